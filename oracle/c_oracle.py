@@ -1,0 +1,126 @@
+"""ctypes front-end of the C oracle (oracle/ses_oracle.c).
+
+TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; the product path under
+simple-es_amd/ never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libses_oracle.so")
+
+MODE_EPISODIC = 0
+MODE_FIXED_LENGTH = 1
+HIDDEN = 32
+
+
+def build(force=False):
+    """Compile the C restatement with the recipe in oracle/Makefile."""
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ses_oracle.c", "ses_oracle_math.h"))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m:
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+        _lib.o_param_count.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def param_count(S, A, gru):
+    return lib().o_param_count(int(S), int(A), int(bool(gru)))
+
+
+def philox_raw(ctr, key):
+    ctr = np.ascontiguousarray(ctr, dtype=np.uint32)
+    key = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.empty(4, dtype=np.uint32)
+    lib().o_philox_raw(_p(ctr), _p(key), _p(out))
+    return out
+
+
+def noise(seed, gen, first_row, n_rows, P):
+    eps = np.empty((n_rows, P), dtype=np.float32)
+    lib().o_noise(ctypes.c_uint64(seed), ctypes.c_uint64(gen), ctypes.c_int64(first_row),
+                  ctypes.c_int(n_rows), ctypes.c_int(P), _p(eps))
+    return eps
+
+
+def perturb(parents, parent_idx, sigma, seed, gen, first_row, n_rows):
+    parents = np.atleast_2d(_f32(parents))
+    P = parents.shape[1]
+    pidx = None if parent_idx is None else np.ascontiguousarray(parent_idx, dtype=np.int32)
+    theta = np.empty((n_rows, P), dtype=np.float32)
+    lib().o_perturb(_p(parents), _p(pidx), ctypes.c_float(sigma), ctypes.c_uint64(seed), ctypes.c_uint64(gen),
+                    ctypes.c_int64(first_row), ctypes.c_int(n_rows), ctypes.c_int(P), _p(theta))
+    return theta
+
+
+def init_states_uniform(seed, gen, first_row, n_rows, E, S, shared, lo=-0.05, hi=0.05):
+    out = np.empty((n_rows, E, S), dtype=np.float32)
+    lib().o_init_states_uniform(ctypes.c_uint64(seed), ctypes.c_uint64(gen), ctypes.c_int64(first_row),
+                                ctypes.c_int(n_rows), ctypes.c_int(E), ctypes.c_int(S), ctypes.c_int(int(shared)),
+                                ctypes.c_float(lo), ctypes.c_float(hi), _p(out))
+    return out
+
+
+def policy_forward(S, A, discrete, gru, theta, obs, h=None):
+    """n independent forwards.  Returns (action[n] i32, logits[n,A], act[n,A], h_next or None)."""
+    theta = np.atleast_2d(_f32(theta))
+    obs = np.atleast_2d(_f32(obs))
+    n = obs.shape[0]
+    assert theta.shape == (n, param_count(S, A, gru)), theta.shape
+    logits = np.empty((n, A), dtype=np.float32)
+    act = np.empty((n, A), dtype=np.float32)
+    action = np.empty(n, dtype=np.int32)
+    hh = None
+    if gru:
+        hh = np.zeros((n, HIDDEN), dtype=np.float32) if h is None else _f32(h).copy()
+    lib().o_policy_forward(ctypes.c_int(S), ctypes.c_int(A), ctypes.c_int(int(discrete)), ctypes.c_int(int(gru)),
+                           ctypes.c_int(n), _p(theta), _p(obs), _p(hh), _p(logits), _p(act), _p(action))
+    return action, logits, act, hh
+
+
+def cartpole_step_soa(mode, max_step, x, xd, th, thd, action, ret, status):
+    """In-place SoA step (arrays must be contiguous f32 / i32 / u32)."""
+    n = x.shape[0]
+    lib().o_cartpole_step_soa(ctypes.c_int(n), ctypes.c_int(mode), ctypes.c_int(max_step),
+                              _p(x), _p(xd), _p(th), _p(thd), _p(action), _p(ret), _p(status))
+
+
+def rollout_cartpole(theta, init, E, max_step, *, S=4, A=2, discrete=True, gru=False,
+                     mode=MODE_EPISODIC, obs_mask=0):
+    """Returns (fitness[N] f32, ep_return[N,E] f64, ep_steps[N,E] i32)."""
+    theta = np.atleast_2d(_f32(theta))
+    N = theta.shape[0]
+    init = _f32(init)
+    per = 1 if init.ndim == 3 else 0
+    assert init.shape[-2:] == (E, 4), init.shape
+    if per:
+        assert init.shape[0] == N
+    ep_ret = np.empty((N, E), dtype=np.float64)
+    ep_steps = np.empty((N, E), dtype=np.int32)
+    fit = np.empty(N, dtype=np.float32)
+    lib().o_rollout_cartpole(ctypes.c_int(S), ctypes.c_int(A), ctypes.c_int(int(discrete)), ctypes.c_int(int(gru)),
+                             ctypes.c_int(N), ctypes.c_int(E), ctypes.c_int(max_step), ctypes.c_int(mode),
+                             ctypes.c_uint32(obs_mask), _p(theta), _p(init), ctypes.c_int(per),
+                             _p(ep_ret), _p(ep_steps), _p(fit))
+    return fit, ep_ret, ep_steps

@@ -1,0 +1,138 @@
+/*
+ * ses_oracle_math.h -- TEST INFRASTRUCTURE (oracle). Not part of the product path.
+ *
+ * Deterministic fp32 elementary functions used by the CPU oracle.  They are
+ * built only from IEEE-754 correctly rounded primitives (+, -, *, fma, /, sqrt,
+ * round-to-nearest-even, int<->float conversion, integer bit operations), so a
+ * HIP kernel that evaluates the same expression tree on gfx950 produces
+ * bit-identical results.  libm / hardware transcendental approximations are
+ * deliberately NOT used: the reference's discrete-action rollouts
+ * (/root/reference/networks/neural_network.py:29-31 argmax) are chaotic in the
+ * last ulp, so the only way to have "returns identical to the CPU reference"
+ * is to pin every rounding.
+ *
+ * Accuracy (measured by tests/test_oracle_math.py against float64 libm):
+ *   o_expf <= 1 ulp on [-86, 88]; o_tanhf <= 2.5 ulp; o_sigmoidf <= 2 ulp;
+ *   o_sincosf <= 1.5 ulp for |x| <= 8192; o_logf <= 1 ulp on (0, 1].
+ * Polynomial coefficients are the classic single-precision Cephes minimax
+ * sets (public domain, S. Moshier) -- they are data, re-used here.
+ *
+ * Must be compiled with -ffp-contract=off (every fma below is explicit).
+ */
+#ifndef SES_ORACLE_MATH_H
+#define SES_ORACLE_MATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+static inline float o_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+static inline uint32_t o_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float o_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+static inline float o_minf(float a, float b) { return a < b ? a : b; }
+static inline float o_maxf(float a, float b) { return a > b ? a : b; }
+
+/* e^x for x clamped to [-86, 88]; result always a normal float. */
+static inline float o_expf(float x)
+{
+    x = o_minf(o_maxf(x, -86.0f), 88.0f);
+    const float k = __builtin_rintf(x * 0x1.715476p+0f);          /* x*log2(e), RNE */
+    float r = o_fma(k, -0.693359375f, x);                          /* Cody-Waite ln2 hi */
+    r = o_fma(k, 2.12194440e-4f, r);                               /* ln2 lo (hi+lo=ln2) */
+    float p = 1.9875691500e-4f;
+    p = o_fma(p, r, 1.3981999507e-3f);
+    p = o_fma(p, r, 8.3334519073e-3f);
+    p = o_fma(p, r, 4.1665795894e-2f);
+    p = o_fma(p, r, 1.6666665459e-1f);
+    p = o_fma(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    float e = o_fma(p, r2, r);
+    e = e + 1.0f;
+    /* scale by 2^k with an integer add on the exponent field (k in [-124,127]) */
+    const int32_t ki = (int32_t)k;
+    return o_u2f(o_f2u(e) + ((uint32_t)ki << 23));
+}
+
+/* tanh: odd polynomial below 0.625, 1 - 2/(e^{2|x|}+1) above. */
+static inline float o_tanhf(float x)
+{
+    const float ax = fabsf(x);
+    const float z = x * x;
+    float p = -5.70498872745e-3f;
+    p = o_fma(p, z, 2.06390887954e-2f);
+    p = o_fma(p, z, -5.37397155531e-2f);
+    p = o_fma(p, z, 1.33314422036e-1f);
+    p = o_fma(p, z, -3.33332819422e-1f);
+    const float small = o_fma(p * z, x, x);
+    const float t = o_expf(2.0f * o_minf(ax, 10.0f));
+    float big = 1.0f - 2.0f / (t + 1.0f);
+    big = copysignf(big, x);
+    return ax < 0.625f ? small : big;
+}
+
+/* logistic sigmoid 1/(1+e^-x) (torch.sigmoid semantics inside nn.GRU). */
+static inline float o_sigmoidf(float x)
+{
+    const float t = o_expf(-x);
+    return 1.0f / (1.0f + t);
+}
+
+/* sin and cos together; Cody-Waite reduction by pi/2, valid to |x| ~ 8192,
+ * degrades gracefully (still deterministic) beyond. */
+static inline void o_sincosf(float x, float *s_out, float *c_out)
+{
+    const float k = __builtin_rintf(x * 0x1.45f306p-1f);          /* x * 2/pi */
+    float r = o_fma(k, -0x1.921p+0f, x);
+    r = o_fma(k, -0x1.f6ap-13f, r);
+    r = o_fma(k, -0x1.110b46p-26f, r);
+    const float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = o_fma(ps, z, 8.3321608736e-3f);
+    ps = o_fma(ps, z, -1.6666654611e-1f);
+    const float s = o_fma(ps * z, r, r);
+    float pc = 2.443315711809948e-5f;
+    pc = o_fma(pc, z, -1.388731625493765e-3f);
+    pc = o_fma(pc, z, 4.166664568298827e-2f);
+    float c = o_fma(pc * z, z, o_fma(-0.5f, z, 1.0f));
+    /* clamp k so the int conversion is defined for huge |x| */
+    const int32_t q = (int32_t)o_minf(o_maxf(k, -1.0e9f), 1.0e9f);
+    const float sv = (q & 1) ? c : s;
+    const float cv = (q & 1) ? s : c;
+    *s_out = (q & 2) ? -sv : sv;
+    *c_out = ((q + 1) & 2) ? -cv : cv;
+}
+
+/* natural log for x in (0, +inf), normal inputs only (callers pass u in [2^-33, 1]). */
+static inline float o_logf(float x)
+{
+    uint32_t u = o_f2u(x);
+    int32_t e = (int32_t)(u >> 23) - 126;                          /* frexp: m in [0.5,1) */
+    float m = o_u2f((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = (m + m) - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    const float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = o_fma(p, m, -1.1514610310e-1f);
+    p = o_fma(p, m, 1.1676998740e-1f);
+    p = o_fma(p, m, -1.2420140846e-1f);
+    p = o_fma(p, m, 1.4249322787e-1f);
+    p = o_fma(p, m, -1.6668057665e-1f);
+    p = o_fma(p, m, 2.0000714765e-1f);
+    p = o_fma(p, m, -2.4999993993e-1f);
+    p = o_fma(p, m, 3.3333331174e-1f);
+    const float fe = (float)e;
+    float y = (p * m) * z;
+    y = o_fma(fe, -2.12194440e-4f, y);
+    y = o_fma(-0.5f, z, y);
+    float r = m + y;
+    r = o_fma(fe, 0.693359375f, r);
+    return r;
+}
+
+#endif /* SES_ORACLE_MATH_H */

@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by IMPORTING the reference.
+
+Run in the build container only (needs /root/reference, which never travels):
+
+    python tests/golden/make_golden.py
+
+What is imported from the reference (read-only, nothing is copied):
+    networks.neural_network.GymEnvModel
+    learning_strategies.evolution.offspring_strategies.{openai_es, simple_evolution, simple_genetic}
+    learning_strategies.optimizers.Adam               (through openai_es)
+    learning_strategies.evolution.loop.{RolloutWorker, ESLoop}   (wandb stubbed: loop.py:10)
+`builder`, `run_es`, `envs.*` cannot be imported (gym / pettingzoo are not installed), so the
+env object handed to RolloutWorker / ESLoop is oracle.cartpole_env.CartPoleF32Env -- the
+build's own fp32 CartPole -- replaying explicit initial states.
+
+The fixtures hold inputs and the reference's outputs only (npz/json data).
+"""
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+sys.modules["wandb"] = types.ModuleType("wandb")
+
+from networks.neural_network import GymEnvModel  # noqa: E402  (reference)
+from learning_strategies.evolution.offspring_strategies import (  # noqa: E402  (reference)
+    openai_es, simple_evolution, simple_genetic)
+from learning_strategies.evolution.loop import RolloutWorker, ESLoop  # noqa: E402  (reference)
+
+from oracle.cartpole_env import CartPoleF32Env, CartPoleGym64Env  # noqa: E402
+
+torch.set_num_threads(1)
+
+
+def set_seed(seed):  # what run_es.py:9-12 does
+    import random
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def flat(model):
+    return np.concatenate([p.reshape(-1) for p in model.get_param_list()]).astype(np.float32)
+
+
+def load_flat(model, vec):
+    out, off = [], 0
+    for p in model.get_param_list():
+        out.append(np.asarray(vec[off:off + p.size], dtype=np.float32).reshape(p.shape))
+        off += p.size
+    model.apply_param(out)
+
+
+def pop_matrix(offspring_group):
+    return np.stack([flat(g["0"]) for g in offspring_group])
+
+
+# --------------------------------------------------------------------------- G1
+def g1_forward():
+    cfgs = [(4, 2, True, False), (4, 2, True, True), (8, 4, False, True), (8, 4, False, False),
+            (12, 5, True, False), (18, 5, True, False), (4, 2, False, True)]
+    out = {}
+    rng = np.random.RandomState(1234)
+    for ci, (S, A, disc, gru) in enumerate(cfgs):
+        nets, T = 6, 24
+        model = GymEnvModel(S, A, disc, gru)
+        P = flat(model).size
+        theta = (rng.standard_normal((nets, P)) * rng.choice([0.1, 0.5, 1.5], size=(nets, 1))).astype(np.float32)
+        obs = (rng.standard_normal((nets, T, S)) * rng.choice([0.05, 1.0, 3.0], size=(nets, 1, 1))).astype(np.float32)
+        obs[:, 0, :] = 0.0                      # all-zero obs (POMDP-like) on the first step
+        acts = np.zeros((nets, T, A if not disc else 1), dtype=np.float32)
+        logits = np.zeros((nets, T, A), dtype=np.float32)
+        hid = np.zeros((nets, T, 32), dtype=np.float32)
+        for n in range(nets):
+            load_flat(model, theta[n])
+            model.reset()
+            for t in range(T):
+                if gru:
+                    h_before = model.h.clone()
+                a = model(obs[n, t][np.newaxis, ...])
+                acts[n, t] = a
+                # pre-activation fc2 output, recomputed with the reference module's own layers
+                with torch.no_grad():
+                    x = torch.tanh(model.fc1(torch.from_numpy(obs[n, t][np.newaxis, ...]).float().unsqueeze(0)))
+                    if gru:
+                        x, _ = model.gru(x, h_before)
+                        x = torch.tanh(x)
+                        hid[n, t] = model.h.numpy().reshape(-1)
+                    logits[n, t] = model.fc2(x).numpy().reshape(-1)
+        key = f"c{ci}"
+        out[key + "_cfg"] = np.array([S, A, int(disc), int(gru)], dtype=np.int32)
+        out[key + "_theta"] = theta
+        out[key + "_obs"] = obs
+        out[key + "_act"] = acts
+        out[key + "_logits"] = logits
+        out[key + "_h"] = hid
+    # zero-initialised network -> action 0 (first-max tie rule)
+    m = GymEnvModel(4, 2, True, False)
+    m.zero_init()
+    out["zero_init_action"] = np.array(m(np.ones((1, 4), dtype=np.float32)), dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "g1_forward.npz"), **out)
+    print("G1 written", {k: v.shape for k, v in out.items() if k.endswith("_theta")})
+
+
+# --------------------------------------------------------------------------- G2-G4
+def synthetic_rewards(n, gen, seed=99):
+    """tie-free deterministic rewards, independent of the global numpy stream"""
+    r = np.random.RandomState(seed + 1000 * gen).permutation(n).astype(np.float64)
+    return list(r * 1.5 + 0.25)
+
+
+def g234_strategies():
+    out = {}
+    meta = {}
+    cases = [
+        ("es_mlp", lambda: openai_es(0.1, 0.999, 0.05, 16), (4, 2, True, False)),
+        ("es_gru", lambda: openai_es(0.168, 0.9999, 0.087, 6), (8, 4, False, True)),
+        ("evo_mlp", lambda: simple_evolution(2.0, 0.9999, 4, 16), (4, 2, True, False)),
+        ("evo_k1", lambda: simple_evolution(1.0, 0.99, 1, 8), (4, 2, True, False)),
+        ("gen_mlp", lambda: simple_genetic(1.0, 0.99, 4, 18), (4, 2, True, False)),
+    ]
+    for name, make, (S, A, disc, gru) in cases:
+        set_seed(7)
+        strat = make()
+        net = GymEnvModel(S, A, disc, gru)
+        net.zero_init()                                   # ESLoop.__init__ does this (loop.py:31)
+        pop = strat.init_offspring(net, ["0"])
+        gens = 4
+        out[f"{name}_theta0"] = pop_matrix(pop)
+        meta[name] = {"cfg": [S, A, int(disc), int(gru)], "seed": 7, "gens": gens, "sigma": [], "best": [],
+                      "pop": [len(pop)]}
+        for g in range(gens):
+            rewards = synthetic_rewards(len(pop), g)
+            out[f"{name}_rewards{g}"] = np.array(rewards)
+            pop, best, sigma = strat.evaluate(rewards)
+            out[f"{name}_theta{g + 1}"] = pop_matrix(pop)
+            out[f"{name}_elite{g + 1}"] = flat(strat.get_elite_model())
+            meta[name]["sigma"].append(float(sigma))
+            meta[name]["best"].append(float(best))
+            meta[name]["pop"].append(len(pop))
+            if isinstance(strat, openai_es):
+                out[f"{name}_mu{g + 1}"] = flat(strat.mu_model)
+                out[f"{name}_m{g + 1}"] = np.concatenate([x.reshape(-1) for x in strat.optimizer.m])
+                out[f"{name}_v{g + 1}"] = np.concatenate([x.reshape(-1) for x in strat.optimizer.v])
+                out[f"{name}_eps{g + 1}"] = np.stack([flat(e) for e in strat.epsilons])
+    # evaluate() with ties in the rewards: only tie-invariant outputs are recorded (best reward, and for
+    # openai_es the multiset of shaped weights) because numpy's default argsort is unstable.
+    set_seed(3)
+    strat = openai_es(0.1, 1.0, 0.05, 16)
+    net = GymEnvModel(4, 2, True, False)
+    net.zero_init()
+    strat.init_offspring(net, ["0"])
+    tied = [10.0] * 6 + [500.0] * 5 + [37.0, 12.0, 99.0, 98.0, 11.0]
+    out["es_tied_rewards"] = np.array(tied)
+    _, best, _ = strat.evaluate(tied)
+    meta["es_tied"] = {"best": float(best)}
+    np.savez_compressed(os.path.join(HERE, "g234_strategies.npz"), **out)
+    with open(os.path.join(HERE, "g234_strategies.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("G2-4 written", list(meta))
+
+
+# --------------------------------------------------------------------------- G5 / G6
+def g56_rollouts():
+    out = {}
+    meta = {}
+    E = 5
+    init = np.random.RandomState(0).uniform(-0.05, 0.05, (E, 4)).astype(np.float32)
+    out["init_states"] = init
+
+    # G6: the reference ESLoop end to end (cartpole.yaml strategy block, smaller population),
+    # process_num=1, our replay env.  Population matrices + returns are captured per generation
+    # by wrapping evaluate.
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    try:
+        for tag, gru, pomdp, gens, offs in (("mlp", False, False, 6, 48), ("gru", True, True, 4, 12)):
+            set_seed(0)
+            env = CartPoleF32Env(init, max_step=500, pomdp=pomdp)
+            net = GymEnvModel(4, 2, True, gru)
+            strat = simple_evolution(2.0, 0.9999, 6, offs)
+            loop = ESLoop({}, strat, env, net, gens, 1, E, False, 10 ** 9)
+            trace = {"rewards": [], "theta": [], "best": [], "sigma": []}
+            orig_eval = strat.evaluate
+            orig_init = strat.init_offspring
+
+            def init_wrapped(network, agent_ids, _o=orig_init, _t=trace):
+                pop = _o(network, agent_ids)
+                _t["theta"].append(pop_matrix(pop))
+                return pop
+
+            def eval_wrapped(rewards, _o=orig_eval, _t=trace):
+                _t["rewards"].append(np.array(rewards, dtype=np.float64))
+                pop, best, sigma = _o(rewards)
+                _t["theta"].append(pop_matrix(pop))
+                _t["best"].append(float(best))
+                _t["sigma"].append(float(sigma))
+                return pop, best, sigma
+
+            strat.init_offspring = init_wrapped
+            strat.evaluate = eval_wrapped
+            loop.run()
+            for g in range(gens):
+                out[f"g6_{tag}_theta{g}"] = trace["theta"][g]
+                out[f"g6_{tag}_returns{g}"] = trace["rewards"][g]
+            meta[f"g6_{tag}"] = {"gens": gens, "best": trace["best"], "sigma": trace["sigma"], "E": E,
+                                 "pomdp": pomdp, "gru": gru, "offspring_num": offs, "elite_num": 6,
+                                 "init_sigma": 2.0, "sigma_decay": 0.9999, "seed": 0}
+            print("G6", tag, "best per generation", trace["best"])
+    finally:
+        os.chdir(cwd)
+
+    # G5: reference RolloutWorker + reference GymEnvModel over our replay env, N=256 diverse policies:
+    # half random (sigma 0.5 / 2.0 from np.random.seed(0)), half taken from the last G6 populations
+    # (trained, long episodes).
+    np.random.seed(0)
+    P = 226
+    theta_rand = np.concatenate([np.random.normal(size=(80, P)) * 0.5, np.random.normal(size=(80, P)) * 2.0])
+    theta = np.concatenate([theta_rand.astype(np.float32), out["g6_mlp_theta5"], out["g6_mlp_theta4"]])[:256]
+    theta = np.ascontiguousarray(theta, dtype=np.float32)
+    net = GymEnvModel(4, 2, True, False)
+    rets32, rets64 = [], []
+    env32 = CartPoleF32Env(init, max_step=500)
+    env64 = CartPoleGym64Env(init, max_step=500)
+    for i in range(theta.shape[0]):
+        load_flat(net, theta[i])
+        env32.rewind()
+        env64.rewind()
+        rets32.append(RolloutWorker((env32, {"0": net}, E)))
+        rets64.append(RolloutWorker((env64, {"0": net}, E)))
+    out["g5_theta"] = theta
+    out["g5_returns"] = np.array(rets32, dtype=np.float64)
+    out["g5_returns_gym64"] = np.array(rets64, dtype=np.float64)
+    meta["g5"] = {"N": int(theta.shape[0]), "E": E, "max_step": 500,
+                  "mean_return": float(np.mean(rets32)),
+                  "frac_equal_f32_vs_gym64": float(np.mean(np.array(rets32) == np.array(rets64)))}
+    print("G5", meta["g5"])
+
+    # G5-gru: POMDP CartPole, GRU policy (README.md:42 headline setting), N=29
+    Pg = 6562
+    np.random.seed(1)
+    theta_g = np.concatenate([(np.random.normal(size=(16, Pg)) * 0.3).astype(np.float32), out["g6_gru_theta3"]])[:32]
+    theta_g = np.ascontiguousarray(theta_g, dtype=np.float32)
+    netg = GymEnvModel(4, 2, True, True)
+    envp = CartPoleF32Env(init, max_step=500, pomdp=True)
+    rg = []
+    for i in range(theta_g.shape[0]):
+        load_flat(netg, theta_g[i])
+        envp.rewind()
+        rg.append(RolloutWorker((envp, {"0": netg}, E)))
+    out["g5gru_theta"] = theta_g
+    out["g5gru_returns"] = np.array(rg, dtype=np.float64)
+    meta["g5gru"] = {"N": int(theta_g.shape[0]), "mean_return": float(np.mean(rg))}
+    print("G5-gru", meta["g5gru"])
+
+    np.savez_compressed(os.path.join(HERE, "g56_rollouts.npz"), **out)
+    with open(os.path.join(HERE, "g56_rollouts.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g234", "g56"]
+    if "g1" in which:
+        g1_forward()
+    if "g234" in which:
+        g234_strategies()
+    if "g56" in which:
+        g56_rollouts()
