@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the simple-es population rollout + fitness loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+Workload (BASELINE.json metric / configs[1]): CartPole-v1, openai_es, MLP policy (P = 226),
+4096 offspring PER GPU, eval_ep_num = 5, synthetic fixed-length episodes of 500 steps (termination
+masked: every counted env-step is a full policy forward + physics step).  One "step" = one
+generation of the hot path, everything on device:
+    Philox perturbation -> fused rollout kernel -> fitness all-gather (RCCL, N > 1) ->
+    rank-centring -> ES gradient + Adam.
+Inputs (mu, Adam moments, initial states) are resident in HBM before the timed region.
+
+Extra legs (rank 0): `roofline` -- the standalone SoA env-step kernel at 2^24 envs against the HBM
+roof (52 algorithmic bytes per env-step), timed with HIP events on the launch stream;
+`cpu_baseline` -- the reference-structured Python multiprocessing port on the host cores (N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "simple-es_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured achievable
+BYTES_PER_ENV_STEP = 52        # 7 dword loads + 6 dword stores
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--offspring-per-gpu", type=int, default=4096)
+    ap.add_argument("--eval-ep-num", type=int, default=5)
+    ap.add_argument("--max-step", type=int, default=500)
+    ap.add_argument("--lanes-per-env", type=int, default=0)
+    ap.add_argument("--roofline-envs", type=int, default=1 << 24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def env_step_roofline(es, n_env, launches=20):
+    """Average duration of k_env_step_cartpole over `launches` launches, HIP events on the launch stream."""
+    from ses import MODE_FIXED_LENGTH
+    g = torch.Generator(device="cuda").manual_seed(0)
+    st = [(torch.rand(n_env, device="cuda", generator=g) - 0.5) * 0.1 for _ in range(4)]
+    action = (torch.rand(n_env, device="cuda", generator=g) > 0.5).to(torch.int32)
+    ret = torch.zeros(n_env, device="cuda")
+    status = torch.zeros(n_env, dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        es.env_step(*st, action, ret, status, mode=MODE_FIXED_LENGTH)
+    torch.cuda.synchronize()
+    durs = []
+    for _ in range(launches):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()                                   # torch's current stream IS the handle's stream
+        es.env_step(*st, action, ret, status, mode=MODE_FIXED_LENGTH)
+        e1.record()
+        e1.synchronize()
+        durs.append(e0.elapsed_time(e1) * 1e-3)
+    avg = sum(durs) / len(durs)
+    achieved = BYTES_PER_ENV_STEP * n_env / avg / 1e9
+    return {"bound": "hbm", "kernel": "k_env_step_cartpole_v4", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "n_env": n_env, "avg_launch_us": avg * 1e6, "env_steps_per_s": n_env / avg,
+            "bytes_per_env_step": BYTES_PER_ENV_STEP}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from ses import HipES, MODE_FIXED_LENGTH
+
+    n_local, E, T = args.offspring_per_gpu, args.eval_ep_num, args.max_step
+    n_global = n_local * world
+    first = rank * n_local
+    es = HipES("CartPole-v1", 4, 2, True, False, max_step=T, eval_ep_num=E, device=local_rank,
+               lanes_per_env=args.lanes_per_env)
+    lr, sigma0, decay, seed = 0.05, 0.1, 0.999, 0
+    mu, m, v = es.zeros(es.P), es.zeros(es.P), es.zeros(es.P)
+    init = es.init_states_uniform(seed, 0, 0, 1, shared=True)[0].contiguous()      # [E,4], common random numbers
+    theta = es.empty(n_local, es.P)
+    fit_local = es.empty(n_local)
+    fit_all = es.empty(n_global) if world > 1 else fit_local
+    state = {"sigma": sigma0, "t": 0}
+
+    def generation(gen):
+        es.perturb(mu, state["sigma"], seed, gen, first, n_local, out=theta)        # row 0 of a real run is mu itself
+        es.rollout(theta, init, mode=MODE_FIXED_LENGTH, fitness=fit_local)
+        if world > 1:
+            dist.all_gather_into_tensor(fit_all, fit_local)
+        _, w = es.rank_center(fit_all)
+        state["t"] += 1
+        t = state["t"]
+        a = lr * math.sqrt(1 - 0.999 ** t) / (1 - 0.99 ** t)
+        es.es_update_philox(w, seed, gen, lr, state["sigma"], a, mu, m, v, skip_row0=False)
+        state["sigma"] *= decay
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for g in range(args.warmup):
+        generation(g)
+    barrier()
+    t0 = time.perf_counter()
+    for g in range(args.warmup, args.warmup + args.steps):
+        generation(g)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    steps_per_gen = n_global * E * T
+    value = steps_per_gen * args.steps / dt
+    result = {
+        "metric": "env-steps/sec (whole node), CartPole openai_es pop=4096 at 1/2/4/8 GPUs",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "CartPole-v1 openai_es MLP(4-32-2, P=226), fixed-length episodes, termination masked",
+                   "offspring_per_gpu": n_local, "offspring_total": n_global, "eval_ep_num": E, "max_step": T,
+                   "env_steps_per_generation": steps_per_gen, "noise": "rocRAND philox4x32_10",
+                   "parallelism": f"population sharded over {world} GPU(s), fitness all-gather"},
+    }
+    if rank == 0:
+        # per-kernel view of one generation (rank 0, HIP events on the launch stream)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        es.perturb(mu, state["sigma"], seed, 10 ** 6, first, n_local, out=theta)
+        ev[1].record()
+        es.rollout(theta, init, mode=MODE_FIXED_LENGTH, fitness=fit_local)
+        ev[2].record()
+        ev[2].synchronize()
+        roll_ms = ev[1].elapsed_time(ev[2])
+        result["rollout_kernel"] = {"ms": roll_ms, "perturb_ms": ev[0].elapsed_time(ev[1]),
+                                    "env_steps_per_s_one_gpu": n_local * E * T / (roll_ms * 1e-3),
+                                    "bound": "valu-issue/latency (state and weights in VGPRs, no HBM traffic in the loop)"}
+        if not args.no_roofline:
+            result["roofline"] = env_step_roofline(es, args.roofline_envs)
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import ref_port
+            result["cpu_baseline"] = ref_port.time_baseline()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

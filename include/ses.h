@@ -1,0 +1,173 @@
+/*
+ * ses.h -- C ABI of libses_hip.so, the MI355X (gfx950) implementation of the simple-es
+ * population rollout + fitness hot path.
+ *
+ * The reference (jinPrelude/simple-es) is pure Python and has no FFI of its own; its seam is
+ *     results = p.map(RolloutWorker, arguments)                 learning_strategies/evolution/loop.py:66-79
+ *     offsprings, best, sigma = strategy.evaluate(results)      learning_strategies/evolution/loop.py:82-84
+ * Every entry point below names the reference code it replaces.  The Python host
+ * (simple-es_amd/ses/_lib.py) binds them with ctypes; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types.
+ *   - every array argument is a CALLER-OWNED DEVICE pointer (e.g. torch tensor .data_ptr());
+ *     the library never frees or reallocates it.  The handle owns only scratch.
+ *   - calls enqueue work on the handle's HIP stream and return immediately; ses_sync() blocks.
+ *   - return value: SES_OK (0) or a negative SES_ERR_*; ses_last_error() gives a message
+ *     (thread-local).  No C++ exception crosses the boundary.
+ *   - "row" = one offspring's flat parameter vector, float32[P], in torch parameters() order
+ *     (networks/neural_network.py:46-56): fc1.weight(32,S) fc1.bias(32)
+ *     [gru.weight_ih(96,32) gru.weight_hh(96,32) gru.bias_ih(96) gru.bias_hh(96)]
+ *     fc2.weight(A,32) fc2.bias(A).
+ *   - results are index-ordered like Pool.map: fitness[i] belongs to row i.
+ */
+#ifndef SES_H_
+#define SES_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SES_OK 0
+#define SES_ERR_INVALID_ARG (-1)
+#define SES_ERR_UNSUPPORTED (-2)
+#define SES_ERR_HIP (-3)
+#define SES_ERR_NO_DEVICE (-4)
+
+#define SES_HIDDEN 32 /* hidden width, hard-coded in networks/neural_network.py:12-17 */
+
+/* env_id */
+#define SES_ENV_NONE (-1)  /* no env: handle only serves policy-forward / strategy kernels */
+#define SES_ENV_CARTPOLE 0 /* CartPole-v1 via envs/gym_wrapper.py:7-54 (conf/cartpole.yaml) */
+
+/* rollout / env-step mode */
+#define SES_MODE_EPISODIC 0     /* an env stops at done (reference semantics, loop.py:116)      */
+#define SES_MODE_FIXED_LENGTH 1 /* synthetic-benchmark mode: physics keeps stepping after done, */
+                                /* rewards gated by the alive flag; identical returns            */
+
+typedef struct ses_handle ses_handle;
+
+typedef struct ses_config {
+    int32_t env_id;          /* SES_ENV_*                                                        */
+    int32_t num_state;       /* network.num_state   (conf/cartpole.yaml:7)                       */
+    int32_t num_action;      /* network.num_action  (conf/cartpole.yaml:8)                       */
+    int32_t discrete_action; /* network.discrete_action                                          */
+    int32_t gru;             /* network.gru                                                      */
+    int32_t pomdp;           /* env.pomdp: CartPolePOMDP zeroes obs[1], obs[3] (gym_wrapper.py:69-77) */
+    int32_t max_step;        /* env.max_step (gym_wrapper.py:37-39); CartPole-v1 TimeLimit = 500 */
+    int32_t eval_ep_num;     /* --eval-ep-num, run_es.py:33-38                                   */
+    int32_t device;          /* HIP device ordinal                                               */
+    int32_t lanes_per_env;   /* 0 = choose from the population size; else 1, 2, 4 or 8           */
+} ses_config;
+
+/* ---- lifecycle --------------------------------------------------------------------------- */
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the
+ * device's default stream. */
+int ses_create(const ses_config *cfg, void *stream, ses_handle **out);
+int ses_destroy(ses_handle *h);
+int ses_sync(ses_handle *h);
+const char *ses_last_error(void);
+const char *ses_version(void);
+/* number of parameters P of GymEnvModel(S, A, _, gru)  (networks/neural_network.py:9-18) */
+int ses_param_count(int32_t num_state, int32_t num_action, int32_t gru);
+/* number of visible HIP devices, or a negative error (never initialises a context) */
+int ses_device_count(void);
+
+/* ---- K1: offspring perturbation ---------------------------------------------------------- */
+/*
+ * theta[i,:] = parents[k,:] + sigma * eps(seed, gen, row_i, :)   if parent_idx[i] = k >= 0
+ * theta[i,:] = parents[k,:]                                      if parent_idx[i] = -1-k
+ * row_i = row_ids ? row_ids[i] : first_row + i   (GLOBAL offspring index: the noise is a pure
+ * function of (seed, gen, row, column), so any shard of any GPU count reproduces the same rows).
+ * eps: rocRAND Philox4x32-10 device engine + deterministic Box-Muller.
+ * Replaces the deepcopy + np.random.normal loops of offspring_strategies.py:53-60 (simple_genetic),
+ * :169-176 (simple_evolution), :312-326 (openai_es).  parent_idx == NULL: every row perturbs parent 0.
+ */
+int ses_perturb(ses_handle *h, const float *parents, const int32_t *parent_idx, const int32_t *row_ids,
+                float sigma, uint64_t seed, uint64_t gen, int64_t first_row, int32_t n_rows, float *theta);
+/* the raw normals eps[n_rows, P] of the same stream (tests, diagnostics) */
+int ses_noise(ses_handle *h, uint64_t seed, uint64_t gen, int64_t first_row, int32_t n_rows, float *eps);
+/*
+ * Reference-stream mode: eps64[n_rows,P] are float64 normals drawn on the host from the
+ * reference's own generator (np.random.normal, offspring_strategies.py:57,173,320) and uploaded.
+ *   theta[i,:]        = (float)( (double)parent + eps64 * sigma )   -- offspring_strategies.py:322
+ *   eps_store[i,:]    = (float)( (double)parent + eps64 )           -- :321 (openai_es.epsilons quirk,
+ *                        SURVEY 3.4-4); may be NULL
+ * bit-identical to the reference's float64-then-float32 arithmetic.  np.random.normal(0, sigma) of
+ * :57/:173 is sigma * z on the same gauss stream, so the host always uploads standard normals z.
+ */
+int ses_perturb_host_noise(ses_handle *h, const float *parents, const int32_t *parent_idx,
+                           const double *eps64, double sigma, int32_t n_rows, float *theta,
+                           float *eps_store);
+/* CartPole reset distribution U(lo,hi)^S from the ENV_INIT Philox stream, out[n_rows,E,S];
+ * shared != 0 keys every row as offspring 0 (common random numbers).  The reference never seeds
+ * its env: initial states are an explicit input of this library. */
+int ses_init_states_uniform(ses_handle *h, uint64_t seed, uint64_t gen, int64_t first_row, int32_t n_rows,
+                            int32_t shared, float lo, float hi, float *out);
+
+/* ---- K2: population-batched policy forward (networks/neural_network.py:20-36) ------------- */
+/* n independent (row, observation[, hidden]) triples.  hidden: float32[n,32] in/out, NULL for MLP.
+ * logits[n,A]: fc2 pre-activation; act[n,A] (may be NULL): tanh(logits), the continuous action;
+ * action[n]: argmax(logits), first maximum wins (== torch.argmax(softmax) up to fp ties). */
+int ses_policy_forward(ses_handle *h, const float *theta, const float *obs, float *hidden, int32_t n,
+                       float *logits, float *act, int32_t *action);
+
+/* ---- K3: SoA env step (envs/gym_wrapper.py:32-45 around the third-party gym physics) ------- */
+/* CartPole, one lane = one env, fp32 state in structure-of-arrays form.
+ * status[i]: bits 0..30 steps taken, bit 31 done.  ret[i] += 1 per live step.
+ * Algorithmic traffic 52 B / env-step: loads x,xd,th,thd,action,ret,status; stores all but action. */
+int ses_env_step(ses_handle *h, int32_t n, int32_t mode, float *x, float *xd, float *th, float *thd,
+                 const int32_t *action, float *ret, uint32_t *status);
+
+/* ---- fused rollout: RolloutWorker for the whole shard (loop.py:108-125) -------------------- */
+/*
+ * theta[n_rows,P]; init: float32 [E,S] (init_per_offspring = 0, shared) or [n_rows,E,S].
+ * fitness[n_rows] = sum over the E episodes of the undiscounted return / E  (loop.py:124).
+ * ep_return (float64[n_rows,E]) and ep_steps (int32[n_rows,E]) may be NULL.
+ * The whole episode loop (policy forward + env step, <= max_step iterations) runs inside one kernel
+ * with env state, GRU state and the offspring's weights held in registers.
+ */
+int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t init_per_offspring,
+                int32_t n_rows, int32_t mode, float *fitness, double *ep_return, int32_t *ep_steps);
+
+/* ---- K4: rank-centred fitness shaping (offspring_strategies.py:380-398) --------------------- */
+/* rank[i] = number of offspring that beat i (reward descending; ties: higher index first, i.e.
+ * np.flip(np.argsort(kind="stable"))).  weights[i] = ((n-1-rank)/(n-1) - 0.5) / std, float64,
+ * with the closed-form std sqrt((n+1)/(12(n-1))) of the rank grid.  weights may be NULL. */
+int ses_rank_center(ses_handle *h, const float *fitness, int32_t n, int32_t *rank, double *weights);
+
+/* ---- K5: ES gradient + Adam (offspring_strategies.py:400-416, optimizers.py:13-24,42-57) ---- */
+/*
+ * grad = (-lr / (n*sigma)) * sum_i weights[i] * eps_i ;  Adam (beta1 = 0.99, beta2 = 0.999, eps = 1e-8)
+ * with step scale adam_a = lr*sqrt(1-beta2^t)/(1-beta1^t) computed by the host; mu, m, v updated in place.
+ * _philox: eps_i regenerated from (seed, gen, row i) for ALL n rows -- every rank of a multi-GPU job
+ *          computes the identical update without a second collective.  Row 0 has eps = 0
+ *          (offspring_strategies.py:302-310) when skip_row0 != 0.
+ * _stored: eps_store[n,P] from ses_perturb_host_noise, accumulated sequentially in the reference's
+ *          order and precision (float32 accumulator, float64 products) -- bit-exact mirror.
+ * grad_out (float32[P]) may be NULL.
+ */
+int ses_es_update_philox(ses_handle *h, const double *weights, int32_t n, int32_t skip_row0, uint64_t seed,
+                         uint64_t gen, double lr, double sigma, double adam_a, float *mu, float *m, float *v,
+                         float *grad_out);
+int ses_es_update_stored(ses_handle *h, const double *weights, int32_t n, const float *eps_store, double lr,
+                         double sigma, double adam_a, float *mu, float *m, float *v, float *grad_out);
+
+/* ---- K6: elite selection + mean (offspring_strategies.py:112-116, 234-248) ------------------ */
+/* elite_ids[j] = index of the offspring with rank j, j < k. */
+int ses_elite_ids(ses_handle *h, const int32_t *rank, int32_t n, int32_t k, int32_t *elite_ids);
+/* rows[k,P] (the elites, best first) -> mean[P] = ((rows[0] + rows[1]) + ... ) / k in float32, the
+ * reference's in-place order (:241-248).  alias_first[j] != 0 (j >= 1) marks an elite that is the same
+ * module object as elite 0, for which the reference's `mu += elite` doubles the running sum
+ * (SURVEY 3.4-6); NULL = no aliasing. */
+int ses_elite_mean(ses_handle *h, const float *rows, const int32_t *alias_first, int32_t k, float *mean);
+/* dst[i,:] = src[ids[i],:] */
+int ses_gather_rows(ses_handle *h, const float *src, const int32_t *ids, int32_t n_ids, float *dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SES_H_ */

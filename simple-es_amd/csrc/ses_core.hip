@@ -1,0 +1,103 @@
+// ses_core.hip -- handle lifecycle and error reporting of libses_hip.so (see include/ses.h)
+#include <cstring>
+#include <string>
+
+#include "ses_internal.h"
+
+namespace ses {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int ensure_episode_scratch(ses_handle *h, size_t episodes)
+{
+    if (episodes <= h->ep_cap) return SES_OK;
+    if (h->ep_return) SES_HIP_TRY(hipFree(h->ep_return));
+    if (h->ep_steps) SES_HIP_TRY(hipFree(h->ep_steps));
+    h->ep_return = nullptr;
+    h->ep_steps = nullptr;
+    h->ep_cap = 0;
+    SES_HIP_TRY(hipMalloc(&h->ep_return, episodes * sizeof(double)));
+    SES_HIP_TRY(hipMalloc(&h->ep_steps, episodes * sizeof(int32_t)));
+    h->ep_cap = episodes;
+    return SES_OK;
+}
+
+}  // namespace ses
+
+extern "C" {
+
+const char *ses_last_error(void) { return ses::g_err; }
+
+const char *ses_version(void) { return "ses-hip 0.1 (gfx950)"; }
+
+int ses_param_count(int32_t S, int32_t A, int32_t gru)
+{
+    int p = SES_HIDDEN * S + SES_HIDDEN + A * SES_HIDDEN + A;
+    if (gru) p += 2 * (3 * SES_HIDDEN * SES_HIDDEN) + 2 * (3 * SES_HIDDEN);
+    return p;
+}
+
+int ses_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return ses::set_error(SES_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
+{
+    SES_REQUIRE(cfg && out, "ses_create: null argument");
+    SES_REQUIRE(cfg->env_id == SES_ENV_CARTPOLE || cfg->env_id == SES_ENV_NONE, "ses_create: unknown env_id %d", cfg->env_id);
+    SES_REQUIRE(cfg->num_state >= 1 && cfg->num_state <= 32, "ses_create: num_state %d out of range", cfg->num_state);
+    SES_REQUIRE(cfg->num_action >= 1 && cfg->num_action <= 8, "ses_create: num_action %d out of range", cfg->num_action);
+    SES_REQUIRE(cfg->eval_ep_num >= 1, "ses_create: eval_ep_num must be >= 1");
+    SES_REQUIRE(cfg->max_step >= 1 && cfg->max_step < (1 << 30), "ses_create: max_step must be in [1, 2^30)");
+    SES_REQUIRE(cfg->lanes_per_env == 0 || cfg->lanes_per_env == 1 || cfg->lanes_per_env == 2 ||
+                    cfg->lanes_per_env == 4 || cfg->lanes_per_env == 8,
+                "ses_create: lanes_per_env must be 0, 1, 2, 4 or 8");
+    if (cfg->env_id == SES_ENV_CARTPOLE)
+        SES_REQUIRE(cfg->num_state == 4 && cfg->num_action == 2 && cfg->discrete_action,
+                    "ses_create: CartPole needs num_state=4 num_action=2 discrete_action=1");
+    int ndev = ses_device_count();
+    if (ndev <= 0) return ses::set_error(SES_ERR_NO_DEVICE, "ses_create: no HIP device visible");
+    SES_REQUIRE(cfg->device >= 0 && cfg->device < ndev, "ses_create: device %d not in [0,%d)", cfg->device, ndev);
+    SES_HIP_TRY(hipSetDevice(cfg->device));
+    ses_handle *h = new ses_handle();
+    std::memset(h, 0, sizeof *h);
+    h->cfg = *cfg;
+    h->stream = (hipStream_t)stream;
+    h->P = ses_param_count(cfg->num_state, cfg->num_action, cfg->gru);
+    h->obs_mask = (cfg->pomdp && cfg->env_id == SES_ENV_CARTPOLE) ? 0xAu : 0u;  // obs[1], obs[3]
+    *out = h;
+    return SES_OK;
+}
+
+int ses_destroy(ses_handle *h)
+{
+    if (!h) return SES_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->ep_return) (void)hipFree(h->ep_return);
+    if (h->ep_steps) (void)hipFree(h->ep_steps);
+    if (h->red_scratch) (void)hipFree(h->red_scratch);
+    delete h;
+    return SES_OK;
+}
+
+int ses_sync(ses_handle *h)
+{
+    SES_REQUIRE(h, "ses_sync: null handle");
+    SES_HIP_TRY(hipStreamSynchronize(h->stream));
+    return SES_OK;
+}
+
+}  // extern "C"

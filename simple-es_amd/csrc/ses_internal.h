@@ -1,0 +1,44 @@
+// ses_internal.h -- handle layout and error plumbing shared by the translation units of libses_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/ses.h"
+
+struct ses_handle {
+    ses_config cfg;
+    hipStream_t stream;
+    int P;               // parameters per offspring
+    uint32_t obs_mask;   // bit k set: observation component k is zeroed (POMDP wrappers)
+    // scratch owned by the handle (grown on demand, never shrunk)
+    double *ep_return;   // [rows * E]
+    int32_t *ep_steps;   // [rows * E]
+    size_t ep_cap;       // capacity in episodes
+    double *red_scratch; // es_update partial sums
+    size_t red_cap;
+};
+
+namespace ses {
+
+int set_error(int code, const char *fmt, ...);
+
+#define SES_HIP_TRY(expr)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return ::ses::set_error(SES_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                    __FILE__, __LINE__);                                           \
+    } while (0)
+
+#define SES_REQUIRE(cond, ...)                                             \
+    do {                                                                   \
+        if (!(cond)) return ::ses::set_error(SES_ERR_INVALID_ARG, __VA_ARGS__); \
+    } while (0)
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+int ensure_episode_scratch(ses_handle *h, size_t episodes);
+
+}  // namespace ses

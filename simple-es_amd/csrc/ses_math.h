@@ -1,0 +1,122 @@
+// ses_math.h -- deterministic fp32 elementary functions for the gfx950 kernels.
+//
+// Every function is an explicit tree of IEEE-754 correctly rounded operations (add, mul, fma,
+// div, sqrt, rndne, cvt, integer ops).  No v_exp/v_log/v_sin/v_rcp approximations and no
+// compiler contraction (build with -ffp-contract=off): the discrete-action rollouts are chaotic
+// in the last ulp, and per-offspring returns must equal the CPU restatement exactly.
+// hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt keeps '/' and sqrtf IEEE-exact
+// (v_div_scale/v_div_fmas/v_div_fixup sequence).
+//
+// Coefficients: single-precision Cephes minimax sets (public domain).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SES_DEV __device__ __forceinline__
+#else
+#define SES_DEV static inline  // host compile of the device functions (tests/hostcheck only)
+#endif
+
+namespace ses {
+
+SES_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+SES_DEV uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+SES_DEV float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+// NaN-absorbing clamp helpers; same value as the oracle's ternaries for every input
+SES_DEV float min_(float a, float b) { return __builtin_fminf(a, b); }
+SES_DEV float max_(float a, float b) { return __builtin_fmaxf(a, b); }
+
+// e^x, x clamped to [-86, 88]
+SES_DEV float exp_(float x)
+{
+    x = min_(max_(x, -86.0f), 88.0f);
+    const float k = __builtin_rintf(x * 0x1.715476p+0f);
+    float r = fma_(k, -0.693359375f, x);
+    r = fma_(k, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fma_(p, r, 1.3981999507e-3f);
+    p = fma_(p, r, 8.3334519073e-3f);
+    p = fma_(p, r, 4.1665795894e-2f);
+    p = fma_(p, r, 1.6666665459e-1f);
+    p = fma_(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    float e = fma_(p, r2, r);
+    e = e + 1.0f;
+    const int32_t ki = (int32_t)k;
+    return u2f(f2u(e) + ((uint32_t)ki << 23));
+}
+
+SES_DEV float tanh_(float x)
+{
+    const float ax = __builtin_fabsf(x);
+    const float z = x * x;
+    float p = -5.70498872745e-3f;
+    p = fma_(p, z, 2.06390887954e-2f);
+    p = fma_(p, z, -5.37397155531e-2f);
+    p = fma_(p, z, 1.33314422036e-1f);
+    p = fma_(p, z, -3.33332819422e-1f);
+    const float small = fma_(p * z, x, x);
+    const float t = exp_(2.0f * min_(ax, 10.0f));
+    float big = 1.0f - 2.0f / (t + 1.0f);
+    big = __builtin_copysignf(big, x);
+    return ax < 0.625f ? small : big;
+}
+
+SES_DEV float sigmoid_(float x)
+{
+    const float t = exp_(-x);
+    return 1.0f / (1.0f + t);
+}
+
+SES_DEV void sincos_(float x, float &s_out, float &c_out)
+{
+    const float k = __builtin_rintf(x * 0x1.45f306p-1f);
+    float r = fma_(k, -0x1.921p+0f, x);
+    r = fma_(k, -0x1.f6ap-13f, r);
+    r = fma_(k, -0x1.110b46p-26f, r);
+    const float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = fma_(ps, z, 8.3321608736e-3f);
+    ps = fma_(ps, z, -1.6666654611e-1f);
+    const float s = fma_(ps * z, r, r);
+    float pc = 2.443315711809948e-5f;
+    pc = fma_(pc, z, -1.388731625493765e-3f);
+    pc = fma_(pc, z, 4.166664568298827e-2f);
+    const float c = fma_(pc * z, z, fma_(-0.5f, z, 1.0f));
+    const int32_t q = (int32_t)min_(max_(k, -1.0e9f), 1.0e9f);
+    const float sv = (q & 1) ? c : s;
+    const float cv = (q & 1) ? s : c;
+    s_out = (q & 2) ? -sv : sv;
+    c_out = ((q + 1) & 2) ? -cv : cv;
+}
+
+// natural log, normal positive inputs
+SES_DEV float log_(float x)
+{
+    const uint32_t u = f2u(x);
+    int32_t e = (int32_t)(u >> 23) - 126;
+    float m = u2f((u & 0x007fffffu) | 0x3f000000u);
+    const bool lo = m < 0.707106781186547524f;
+    e = lo ? e - 1 : e;
+    m = lo ? (m + m) - 1.0f : m - 1.0f;
+    const float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = fma_(p, m, -1.1514610310e-1f);
+    p = fma_(p, m, 1.1676998740e-1f);
+    p = fma_(p, m, -1.2420140846e-1f);
+    p = fma_(p, m, 1.4249322787e-1f);
+    p = fma_(p, m, -1.6668057665e-1f);
+    p = fma_(p, m, 2.0000714765e-1f);
+    p = fma_(p, m, -2.4999993993e-1f);
+    p = fma_(p, m, 3.3333331174e-1f);
+    const float fe = (float)e;
+    float y = (p * m) * z;
+    y = fma_(fe, -2.12194440e-4f, y);
+    y = fma_(-0.5f, z, y);
+    float r = m + y;
+    r = fma_(fe, 0.693359375f, r);
+    return r;
+}
+
+}  // namespace ses

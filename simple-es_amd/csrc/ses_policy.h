@@ -1,0 +1,130 @@
+// ses_policy.h -- GymEnvModel forward (networks/neural_network.py:20-36) for one env, with the
+// 32 hidden units of the MLP spread over LPE adjacent lanes (LPE = 1, 2, 4 or 8).
+//
+// Why lanes-per-env: at the benchmark population (4096 offspring x 5 episodes = 20 480 envs) one
+// lane per env would give 320 wavefronts for 1024 SIMDs.  Splitting the hidden layer over LPE lanes
+// multiplies the wave count and divides the serial work per env-step (the 32 tanh evaluations are
+// the bulk of it) at the cost of a DPP butterfly for the fc2 dot products and redundant physics.
+//
+// Canonical arithmetic (identical for every LPE, restated by oracle/ses_oracle.c):
+//   fc1  : acc = b1[j]; acc = fma(W1[j][k], obs[k], acc) for k ascending; a[j] = tanh(acc)
+//   fc2  : 8 groups of 4 consecutive hidden units, in-order fma chain from the plain product;
+//          balanced pairwise tree over the 8 group sums; + bias last
+//   argmax: first maximum wins
+// Per-offspring weights make the "population GEMM" a batch of 32xS matvecs with M = E = 5 columns
+// per weight set; fp32 MFMA runs at the VALU rate on gfx950 and a 32x32x2 tile would be 84 %
+// padding, so the contraction stays on the VALU with the weights resident in VGPRs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ses_math.h"
+
+namespace ses {
+
+constexpr int H = 32;
+
+// DPP lane exchange; all lanes of the wave must be active
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each group of 8
+
+// sum over the LPE lanes that share one env; every lane ends with the same bits
+template <int LPE>
+__device__ __forceinline__ float lanes_sum(float v)
+{
+    if constexpr (LPE >= 2) v = v + dpp_mov<DPP_QUAD_XOR1>(v);
+    if constexpr (LPE >= 4) v = v + dpp_mov<DPP_QUAD_XOR2>(v);
+    if constexpr (LPE >= 8) v = v + dpp_mov<DPP_ROW_HALF_MIRROR>(v);  // both quads hold their sum already
+    return v;
+}
+
+template <int S, int A, int LPE>
+struct MlpSlice {
+    static constexpr int U = H / LPE;   // hidden units owned by this lane
+    static constexpr int G = U / 4;     // fc2 groups owned by this lane
+    static_assert(U % 4 == 0, "a lane owns whole fc2 groups");
+    float w1[U][S];
+    float b1[U];
+    float w2[A][U];
+    float b2[A];
+
+    // theta: this offspring's row; sub: lane index inside the env's lane group
+    __device__ __forceinline__ void load(const float *__restrict__ theta, int sub)
+    {
+        const int j0 = sub * U;
+        const float *pw1 = theta;
+        const float *pb1 = theta + H * S;
+        const float *pw2 = pb1 + H;
+        const float *pb2 = pw2 + A * H;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) w1[u][k] = pw1[(j0 + u) * S + k];
+            b1[u] = pb1[j0 + u];
+        }
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) w2[a][u] = pw2[a * H + j0 + u];
+            b2[a] = pb2[a];
+        }
+    }
+
+    // obs[S] -> logits[A] (identical in all LPE lanes of the env)
+    __device__ __forceinline__ void forward(const float (&obs)[S], float (&logits)[A]) const
+    {
+        float a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float acc = b1[u];
+#pragma unroll
+            for (int k = 0; k < S; ++k) acc = fma_(w1[u][k], obs[k], acc);
+            a[u] = tanh_(acc);
+        }
+#pragma unroll
+        for (int o = 0; o < A; ++o) {
+            float p[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float acc = w2[o][4 * g] * a[4 * g];
+                acc = fma_(w2[o][4 * g + 1], a[4 * g + 1], acc);
+                acc = fma_(w2[o][4 * g + 2], a[4 * g + 2], acc);
+                acc = fma_(w2[o][4 * g + 3], a[4 * g + 3], acc);
+                p[g] = acc;
+            }
+            // in-lane levels of the balanced tree over the 8 groups
+            float s;
+            if constexpr (G == 8) {
+                s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+            } else if constexpr (G == 4) {
+                s = (p[0] + p[1]) + (p[2] + p[3]);
+            } else if constexpr (G == 2) {
+                s = p[0] + p[1];
+            } else {
+                s = p[0];
+            }
+            logits[o] = lanes_sum<LPE>(s) + b2[o];
+        }
+    }
+};
+
+template <int A>
+__device__ __forceinline__ int argmax_first(const float (&logits)[A])
+{
+    int best = 0;
+    float bv = logits[0];
+#pragma unroll
+    for (int k = 1; k < A; ++k) {
+        const bool gt = logits[k] > bv;
+        best = gt ? k : best;
+        bv = gt ? logits[k] : bv;
+    }
+    return best;
+}
+
+}  // namespace ses

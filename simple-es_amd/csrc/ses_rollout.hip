@@ -1,0 +1,289 @@
+// ses_rollout.hip -- the rollout side of the hot path:
+//   k_rollout_cartpole_mlp : RolloutWorker (loop.py:108-125) for a whole shard, one kernel
+//   k_fitness_mean         : total_reward / eval_ep_num (loop.py:124)
+//   k_env_step_cartpole    : standalone SoA env.step (gym_wrapper.py:32-45), the HBM-roofline kernel
+//   k_policy_forward_mlp   : standalone population-batched GymEnvModel.forward (neural_network.py:20-36)
+#include "ses_cartpole.h"
+#include "ses_internal.h"
+#include "ses_policy.h"
+
+namespace ses {
+
+// ------------------------------------------------------------------------------------------------
+// Fused rollout.  Thread layout: LPE adjacent lanes share one env; envs are numbered
+// env = row * E + episode, so the E episodes of an offspring sit next to each other and their weight
+// loads hit the same cache lines.  Each wave is its own 64-thread workgroup: 20 480 envs x LPE=4 gives
+// 1280 independent workgroups that the dispatcher spreads over the 8 XCDs / 256 CUs; nothing is shared
+// between workgroups, so no XCD-aware remap is needed.
+// All state (4 floats of physics, the lane's slice of the weights, step counter) stays in VGPRs for
+// the whole episode; HBM is touched once at the start (theta row, initial state) and once at the end.
+template <int LPE, bool FIXED_LENGTH>
+__global__ __launch_bounds__(64) void k_rollout_cartpole_mlp(const float *__restrict__ theta,
+                                                             const float *__restrict__ init, int init_per_offspring,
+                                                             int n_rows, int E, int P, int max_step,
+                                                             uint32_t obs_mask, double *__restrict__ ep_return,
+                                                             int32_t *__restrict__ ep_steps)
+{
+    const long long gtid = (long long)blockIdx.x * 64 + threadIdx.x;
+    const int n_env = n_rows * E;
+    int env = (int)(gtid / LPE);
+    const int sub = (int)(threadIdx.x % LPE);
+    const bool valid = env < n_env;
+    env = valid ? env : n_env - 1;  // keep every lane active (DPP needs full waves); only valid lanes store
+    const int row = env / E;
+    const int ep = env - row * E;
+
+    MlpSlice<4, 2, LPE> net;
+    net.load(theta + (size_t)row * P, sub);
+
+    const float *s0 = init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 4;
+    CartPoleState st{s0[0], s0[1], s0[2], s0[3]};
+    int steps = 0;
+    bool alive = true;
+
+    for (int t = 0; t < max_step; ++t) {
+        if constexpr (!FIXED_LENGTH) {
+            if (__ballot(alive) == 0ull) break;  // wave-uniform: every env of this wave is done
+        }
+        float obs[4];
+        obs[0] = (obs_mask & 1u) ? 0.0f : st.x;
+        obs[1] = (obs_mask & 2u) ? 0.0f : st.xd;
+        obs[2] = (obs_mask & 4u) ? 0.0f : st.th;
+        obs[3] = (obs_mask & 8u) ? 0.0f : st.thd;
+        float logits[2];
+        net.forward(obs, logits);
+        const int action = argmax_first<2>(logits);
+        CartPoleState ns = st;
+        const bool term = cartpole_step(ns, action);
+        const bool advance = FIXED_LENGTH ? true : alive;  // episodic: a finished env is frozen
+        st.x = advance ? ns.x : st.x;
+        st.xd = advance ? ns.xd : st.xd;
+        st.th = advance ? ns.th : st.th;
+        st.thd = advance ? ns.thd : st.thd;
+        const int nsteps = steps + 1;
+        const bool finished = term | (nsteps >= max_step);
+        steps = alive ? nsteps : steps;
+        alive = alive & !finished;
+    }
+    if (valid && sub == 0) {
+        if (ep_return) ep_return[env] = (double)steps;  // CartPole reward is 1 per step incl. the terminal one
+        if (ep_steps) ep_steps[env] = steps;
+    }
+}
+
+__global__ void k_fitness_mean(const double *__restrict__ ep_return, int n_rows, int E, float *__restrict__ fitness)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    double total = 0.0;
+    for (int e = 0; e < E; ++e) total += ep_return[(size_t)i * E + e];
+    fitness[i] = (float)(total / (double)E);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Standalone SoA env step: pure streaming, 16 B per lane per array (7 loads + 6 stores = 52 B/env).
+template <bool FIXED_LENGTH>
+__device__ __forceinline__ void env_step_one(float &x, float &xd, float &th, float &thd, int action, float &ret,
+                                             uint32_t &status, int max_step)
+{
+    const bool done = (status >> 31) != 0u;
+    const uint32_t steps = status & 0x7fffffffu;
+    CartPoleState s{x, xd, th, thd};
+    const bool term = cartpole_step(s, action);
+    const bool advance = FIXED_LENGTH ? true : !done;
+    x = advance ? s.x : x;
+    xd = advance ? s.xd : xd;
+    th = advance ? s.th : th;
+    thd = advance ? s.thd : thd;
+    const uint32_t nsteps = steps + 1u;
+    const bool now_done = term | (max_step > 0 && (int)nsteps >= max_step);
+    ret = done ? ret : ret + 1.0f;
+    status = done ? status : (nsteps | ((uint32_t)now_done << 31));
+}
+
+template <bool FIXED_LENGTH>
+__global__ __launch_bounds__(256) void k_env_step_cartpole_v4(int n4, int max_step, float4 *__restrict__ x,
+                                                              float4 *__restrict__ xd, float4 *__restrict__ th,
+                                                              float4 *__restrict__ thd,
+                                                              const int4 *__restrict__ action,
+                                                              float4 *__restrict__ ret, uint4 *__restrict__ status)
+{
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 vx = x[i], vxd = xd[i], vth = th[i], vthd = thd[i], vr = ret[i];
+        const int4 va = action[i];
+        uint4 vs = status[i];
+        env_step_one<FIXED_LENGTH>(vx.x, vxd.x, vth.x, vthd.x, va.x, vr.x, vs.x, max_step);
+        env_step_one<FIXED_LENGTH>(vx.y, vxd.y, vth.y, vthd.y, va.y, vr.y, vs.y, max_step);
+        env_step_one<FIXED_LENGTH>(vx.z, vxd.z, vth.z, vthd.z, va.z, vr.z, vs.z, max_step);
+        env_step_one<FIXED_LENGTH>(vx.w, vxd.w, vth.w, vthd.w, va.w, vr.w, vs.w, max_step);
+        x[i] = vx; xd[i] = vxd; th[i] = vth; thd[i] = vthd; ret[i] = vr; status[i] = vs;
+    }
+}
+
+template <bool FIXED_LENGTH>
+__global__ void k_env_step_cartpole_scalar(int first, int n, int max_step, float *x, float *xd, float *th, float *thd,
+                                           const int32_t *action, float *ret, uint32_t *status)
+{
+    const int i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float vx = x[i], vxd = xd[i], vth = th[i], vthd = thd[i], vr = ret[i];
+    uint32_t vs = status[i];
+    env_step_one<FIXED_LENGTH>(vx, vxd, vth, vthd, action[i], vr, vs, max_step);
+    x[i] = vx; xd[i] = vxd; th[i] = vth; thd[i] = vthd; ret[i] = vr; status[i] = vs;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Standalone MLP forward, 4 lanes per (row, obs) pair.
+template <int S, int A>
+__global__ __launch_bounds__(64) void k_policy_forward_mlp(const float *__restrict__ theta,
+                                                           const float *__restrict__ obs_in, int n, int P,
+                                                           float *__restrict__ logits_out, float *__restrict__ act_out,
+                                                           int32_t *__restrict__ action_out)
+{
+    constexpr int LPE = 4;
+    const long long gtid = (long long)blockIdx.x * 64 + threadIdx.x;
+    int i = (int)(gtid / LPE);
+    const int sub = (int)(threadIdx.x % LPE);
+    const bool valid = i < n;
+    i = valid ? i : n - 1;
+    MlpSlice<S, A, LPE> net;
+    net.load(theta + (size_t)i * P, sub);
+    float obs[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) obs[k] = obs_in[(size_t)i * S + k];
+    float logits[A];
+    net.forward(obs, logits);
+    const int action = argmax_first<A>(logits);
+    if (valid && sub == 0) {
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            logits_out[(size_t)i * A + k] = logits[k];
+            if (act_out) act_out[(size_t)i * A + k] = tanh_(logits[k]);
+        }
+        action_out[i] = action;
+    }
+}
+
+static int pick_lanes_per_env(const ses_handle *h, long long n_env)
+{
+    if (h->cfg.lanes_per_env) return h->cfg.lanes_per_env;
+    // smallest split that still gives every one of the 1024 SIMDs a wavefront
+    for (int lpe = 1; lpe < 8; lpe *= 2)
+        if (n_env * lpe / 64 >= 1024) return lpe;
+    return 8;
+}
+
+template <int LPE>
+static void launch_rollout(const ses_handle *h, const float *theta, const float *init, int per, int n_rows, int mode,
+                           double *ep_return, int32_t *ep_steps)
+{
+    const long long threads = (long long)n_rows * h->cfg.eval_ep_num * LPE;
+    const int blocks = ceil_div(threads, 64);
+    if (mode == SES_MODE_FIXED_LENGTH)
+        hipLaunchKernelGGL((k_rollout_cartpole_mlp<LPE, true>), dim3(blocks), dim3(64), 0, h->stream, theta, init, per,
+                           n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, ep_return, ep_steps);
+    else
+        hipLaunchKernelGGL((k_rollout_cartpole_mlp<LPE, false>), dim3(blocks), dim3(64), 0, h->stream, theta, init, per,
+                           n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, ep_return, ep_steps);
+}
+
+}  // namespace ses
+
+extern "C" {
+
+int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t init_per_offspring, int32_t n_rows,
+                int32_t mode, float *fitness, double *ep_return, int32_t *ep_steps)
+{
+    using namespace ses;
+    SES_REQUIRE(h && theta && init && fitness, "ses_rollout: null argument");
+    SES_REQUIRE(n_rows >= 1, "ses_rollout: n_rows must be >= 1");
+    SES_REQUIRE(mode == SES_MODE_EPISODIC || mode == SES_MODE_FIXED_LENGTH, "ses_rollout: bad mode %d", mode);
+    SES_REQUIRE((long long)n_rows * h->cfg.eval_ep_num * 8 < (1ll << 31), "ses_rollout: shard too large");
+    SES_REQUIRE(h->cfg.env_id == SES_ENV_CARTPOLE, "ses_rollout: handle has no env");
+    if (h->cfg.gru) return set_error(SES_ERR_UNSUPPORTED, "ses_rollout: GRU policy kernel not built yet");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    const size_t episodes = (size_t)n_rows * h->cfg.eval_ep_num;
+    double *epr = ep_return;
+    if (!epr) {
+        int rc = ensure_episode_scratch(h, episodes);
+        if (rc != SES_OK) return rc;
+        epr = h->ep_return;
+    }
+    switch (pick_lanes_per_env(h, (long long)episodes)) {
+        case 1: launch_rollout<1>(h, theta, init, init_per_offspring, n_rows, mode, epr, ep_steps); break;
+        case 2: launch_rollout<2>(h, theta, init, init_per_offspring, n_rows, mode, epr, ep_steps); break;
+        case 4: launch_rollout<4>(h, theta, init, init_per_offspring, n_rows, mode, epr, ep_steps); break;
+        default: launch_rollout<8>(h, theta, init, init_per_offspring, n_rows, mode, epr, ep_steps); break;
+    }
+    hipLaunchKernelGGL(k_fitness_mean, dim3(ceil_div(n_rows, 256)), dim3(256), 0, h->stream, epr, n_rows,
+                       h->cfg.eval_ep_num, fitness);
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+int ses_env_step(ses_handle *h, int32_t n, int32_t mode, float *x, float *xd, float *th, float *thd,
+                 const int32_t *action, float *ret, uint32_t *status)
+{
+    using namespace ses;
+    SES_REQUIRE(h && x && xd && th && thd && action && ret && status, "ses_env_step: null argument");
+    SES_REQUIRE(n >= 1, "ses_env_step: n must be >= 1");
+    SES_REQUIRE(mode == SES_MODE_EPISODIC || mode == SES_MODE_FIXED_LENGTH, "ses_env_step: bad mode %d", mode);
+    SES_REQUIRE(h->cfg.env_id == SES_ENV_CARTPOLE, "ses_env_step: handle has no env");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    const uintptr_t align = (uintptr_t)x | (uintptr_t)xd | (uintptr_t)th | (uintptr_t)thd | (uintptr_t)action |
+                            (uintptr_t)ret | (uintptr_t)status;
+    const int n4 = (align & 15u) ? 0 : n / 4;  // unaligned arrays take the scalar path entirely
+    const int max_step = h->cfg.max_step;
+    if (n4 > 0) {
+        const int blocks = n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048;  // grid-stride beyond 8 blocks per CU
+        if (mode == SES_MODE_FIXED_LENGTH)
+            hipLaunchKernelGGL((k_env_step_cartpole_v4<true>), dim3(blocks), dim3(256), 0, h->stream, n4, max_step,
+                               (float4 *)x, (float4 *)xd, (float4 *)th, (float4 *)thd, (const int4 *)action,
+                               (float4 *)ret, (uint4 *)status);
+        else
+            hipLaunchKernelGGL((k_env_step_cartpole_v4<false>), dim3(blocks), dim3(256), 0, h->stream, n4, max_step,
+                               (float4 *)x, (float4 *)xd, (float4 *)th, (float4 *)thd, (const int4 *)action,
+                               (float4 *)ret, (uint4 *)status);
+    }
+    const int first = n4 * 4;
+    if (first < n) {
+        const int blocks = ceil_div(n - first, 256);
+        if (mode == SES_MODE_FIXED_LENGTH)
+            hipLaunchKernelGGL((k_env_step_cartpole_scalar<true>), dim3(blocks), dim3(256), 0, h->stream, first, n,
+                               max_step, x, xd, th, thd, action, ret, status);
+        else
+            hipLaunchKernelGGL((k_env_step_cartpole_scalar<false>), dim3(blocks), dim3(256), 0, h->stream, first, n,
+                               max_step, x, xd, th, thd, action, ret, status);
+    }
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+int ses_policy_forward(ses_handle *h, const float *theta, const float *obs, float *hidden, int32_t n, float *logits,
+                       float *act, int32_t *action)
+{
+    using namespace ses;
+    SES_REQUIRE(h && theta && obs && logits && action, "ses_policy_forward: null argument");
+    SES_REQUIRE(n >= 1 && (long long)n * 4 < (1ll << 31), "ses_policy_forward: n out of range");
+    if (h->cfg.gru) return set_error(SES_ERR_UNSUPPORTED, "ses_policy_forward: GRU policy kernel not built yet");
+    (void)hidden;
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    const int blocks = ceil_div((long long)n * 4, 64);
+    const int S = h->cfg.num_state, A = h->cfg.num_action;
+#define SES_FWD_CASE(S_, A_)                                                                                      \
+    if (S == S_ && A == A_) {                                                                                     \
+        hipLaunchKernelGGL((k_policy_forward_mlp<S_, A_>), dim3(blocks), dim3(64), 0, h->stream, theta, obs, n, h->P, \
+                           logits, act, action);                                                                  \
+        SES_HIP_TRY(hipGetLastError());                                                                           \
+        return SES_OK;                                                                                            \
+    }
+    SES_FWD_CASE(4, 2)
+    SES_FWD_CASE(8, 4)
+    SES_FWD_CASE(12, 5)
+    SES_FWD_CASE(18, 5)
+#undef SES_FWD_CASE
+    return set_error(SES_ERR_UNSUPPORTED, "ses_policy_forward: no kernel instance for num_state=%d num_action=%d", S, A);
+}
+
+}  // extern "C"

@@ -1,0 +1,367 @@
+// ses_strategy.hip -- the fitness-loop side of the hot path (strategy.evaluate, loop.py:82-84):
+//   K1 perturbation (Philox / host-noise), K4 rank-centring, K5 ES gradient + Adam, K6 elite mean.
+// Reference: learning_strategies/evolution/offspring_strategies.py, learning_strategies/optimizers.py.
+#include "ses_internal.h"
+#include "ses_rng.h"
+
+namespace ses {
+
+// ------------------------------------------------------------------------------------------------ K1
+// one thread = one Philox call = 4 consecutive parameters of one offspring
+__global__ __launch_bounds__(256) void k_perturb(const float *__restrict__ parents,
+                                                 const int32_t *__restrict__ parent_idx,
+                                                 const int32_t *__restrict__ row_ids, float sigma, uint64_t seed,
+                                                 uint64_t gen, long long first_row, int n_rows, int P, int quads,
+                                                 float *__restrict__ theta)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n_rows * quads) return;
+    const int i = (int)(t / quads);
+    const int q = (int)(t - (long long)i * quads);
+    const int32_t pi = parent_idx ? parent_idx[i] : 0;
+    const float *src = parents + (size_t)(pi >= 0 ? pi : -1 - pi) * P + 4 * q;
+    float *dst = theta + (size_t)i * P + 4 * q;
+    const int lim = P - 4 * q < 4 ? P - 4 * q : 4;
+    if (pi < 0) {
+        for (int l = 0; l < lim; ++l) dst[l] = src[l];
+        return;
+    }
+    const uint32_t row = (uint32_t)(row_ids ? (long long)row_ids[i] : first_row + i);
+    float z[4];
+    normal4(seed, gen, row, (uint32_t)q, z);
+    for (int l = 0; l < lim; ++l) dst[l] = fma_(sigma, z[l], src[l]);
+}
+
+__global__ __launch_bounds__(256) void k_noise(uint64_t seed, uint64_t gen, long long first_row, int n_rows, int P,
+                                               int quads, float *__restrict__ eps)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n_rows * quads) return;
+    const int i = (int)(t / quads);
+    const int q = (int)(t - (long long)i * quads);
+    float z[4];
+    normal4(seed, gen, (uint32_t)(first_row + i), (uint32_t)q, z);
+    const int lim = P - 4 * q < 4 ? P - 4 * q : 4;
+    for (int l = 0; l < lim; ++l) eps[(size_t)i * P + 4 * q + l] = z[l];
+}
+
+// float64 host noise, the reference's own rounding: float32(float64(parent) + eps*sigma)
+__global__ __launch_bounds__(256) void k_perturb_host_noise(const float *__restrict__ parents,
+                                                            const int32_t *__restrict__ parent_idx,
+                                                            const double *__restrict__ eps64, double sigma,
+                                                            int n_rows, int P, float *__restrict__ theta,
+                                                            float *__restrict__ eps_store)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n_rows * P) return;
+    const int i = (int)(t / P);
+    const int p = (int)(t - (long long)i * P);
+    const int32_t pi = parent_idx ? parent_idx[i] : 0;
+    const float base = parents[(size_t)(pi >= 0 ? pi : -1 - pi) * P + p];
+    if (pi < 0) {
+        theta[t] = base;
+        if (eps_store) eps_store[t] = base;
+        return;
+    }
+    const double e = eps64[t];
+    const double scaled = e * sigma;                       // offspring_strategies.py:322  epsilon * sigma
+    theta[t] = (float)((double)base + scaled);             // in-place += on a float32 view
+    if (eps_store) eps_store[t] = (float)((double)base + e);  // :321  eps_param += epsilon
+}
+
+__global__ __launch_bounds__(256) void k_init_states_uniform(uint64_t seed, uint64_t gen, long long first_row,
+                                                             int n_rows, int E, int S, int shared, float lo,
+                                                             float span, float *__restrict__ out)
+{
+    const int sq = (S + 3) / 4;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n_rows * E * sq) return;
+    const int q = (int)(t % sq);
+    const int e = (int)((t / sq) % E);
+    const int i = (int)(t / ((long long)sq * E));
+    const uint4 r = philox_words(seed, TAG_ENV_INIT, gen, shared ? 0u : (uint32_t)(first_row + i), (uint32_t)(e * 8 + q));
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    for (int l = 0; l < 4 && 4 * q + l < S; ++l)
+        out[((size_t)i * E + e) * S + 4 * q + l] = fma_(u32_to_unit(w[l]), span, lo);
+}
+
+// ------------------------------------------------------------------------------------------------ K4
+// rank[i] = #{ j : f[j] > f[i]  or (f[j] == f[i] and j > i) }   -- O(n^2) counting with LDS tiles.
+// n <= 65 536 on the benchmark configs: 4.3e9 compares worst case, ~0.1 ms on 256 CUs, and it is exact,
+// order-independent and needs no sort.
+__global__ __launch_bounds__(256) void k_rank_center(const float *__restrict__ fit, int n, int32_t *__restrict__ rank,
+                                                     double *__restrict__ weights)
+{
+    __shared__ float tile[1024];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float fi = i < n ? fit[i] : 0.0f;
+    int count = 0;
+    for (int base = 0; base < n; base += 1024) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < 1024; k += 256) tile[k] = base + k < n ? fit[base + k] : 0.0f;
+        __syncthreads();
+        const int lim = n - base < 1024 ? n - base : 1024;
+        for (int k = 0; k < lim; ++k) {
+            const float fj = tile[k];
+            const int j = base + k;
+            count += (fj > fi) | ((fj == fi) & (j > i));
+        }
+    }
+    if (i < n) {
+        rank[i] = count;
+        if (weights) {
+            const double nm1 = (double)(n - 1);
+            const double centred = ((double)(n - 1 - count) / nm1) - 0.5;
+            const double sd = sqrt((double)(n + 1) / (12.0 * nm1));
+            weights[i] = centred / sd;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K5
+// Adam exactly as optimizers.py:42-57 evaluates it under numpy >= 2 promotion rules:
+// float32 moments, float64 step, float32 parameter store.
+__device__ __forceinline__ void adam_apply(float g, double adam_a, float &mu, float &m, float &v)
+{
+    const float b1 = 0.99f, b2 = 0.999f;
+    const float omb1 = (float)(1.0 - 0.99), omb2 = (float)(1.0 - 0.999);
+    const float mn = (b1 * m) + (omb1 * g);
+    const float vn = (b2 * v) + (omb2 * (g * g));
+    const double num = (-adam_a) * (double)mn;
+    const float den = __builtin_sqrtf(vn) + 1e-08f;
+    const double step = num / (double)den;
+    m = mn;
+    v = vn;
+    mu = (float)((double)mu + step);
+}
+
+// grad[p] = sum_i w_i * eps(i, p) with eps regenerated from Philox.
+// One 256-thread workgroup per parameter quad; thread c accumulates rows c, c+256, ... in ascending
+// order, then a fixed LDS tree combines the 256 partials: bit-reproducible for a given n, on any rank.
+__global__ __launch_bounds__(256) void k_es_update_philox(const double *__restrict__ weights, int n, int skip_row0,
+                                                          uint64_t seed, uint64_t gen, int P, float update_factor,
+                                                          double adam_a, float *__restrict__ mu,
+                                                          float *__restrict__ m, float *__restrict__ v,
+                                                          float *__restrict__ grad_out)
+{
+    __shared__ float red[4][256];
+    const int q = blockIdx.x;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = threadIdx.x; i < n; i += 256) {
+        if (skip_row0 && i == 0) continue;
+        const float w = (float)weights[i];
+        float z[4];
+        normal4(seed, gen, (uint32_t)i, (uint32_t)q, z);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) acc[l] = fma_(w, z[l], acc[l]);
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) red[l][threadIdx.x] = acc[l];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+#pragma unroll
+            for (int l = 0; l < 4; ++l) red[l][threadIdx.x] = red[l][threadIdx.x] + red[l][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) {
+        const int p = 4 * q + threadIdx.x;
+        if (p < P) {
+            const float g = red[threadIdx.x][0] * update_factor;  // offspring_strategies.py:414
+            if (grad_out) grad_out[p] = g;
+            float muv = mu[p], mv = m[p], vv = v[p];
+            adam_apply(g, adam_a, muv, mv, vv);
+            mu[p] = muv; m[p] = mv; v[p] = vv;
+        }
+    }
+}
+
+// Reference-order accumulation over stored (mu + eps) rows: one thread per parameter, sequential over
+// offspring, float32 accumulator with float64 products (offspring_strategies.py:409-414 under numpy 2).
+__global__ __launch_bounds__(64) void k_es_update_stored(const double *__restrict__ weights, int n,
+                                                         const float *__restrict__ eps_store, int P,
+                                                         float update_factor, double adam_a, float *__restrict__ mu,
+                                                         float *__restrict__ m, float *__restrict__ v,
+                                                         float *__restrict__ grad_out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float acc = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        const double prod = (double)eps_store[(size_t)i * P + p] * weights[i];
+        acc = (float)((double)acc + prod);
+    }
+    const float g = acc * update_factor;
+    if (grad_out) grad_out[p] = g;
+    float muv = mu[p], mv = m[p], vv = v[p];
+    adam_apply(g, adam_a, muv, mv, vv);
+    mu[p] = muv; m[p] = mv; v[p] = vv;
+}
+
+// ------------------------------------------------------------------------------------------------ K6
+__global__ void k_elite_ids(const int32_t *__restrict__ rank, int n, int k, int32_t *__restrict__ elite_ids)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && rank[i] < k) elite_ids[rank[i]] = i;
+}
+
+__global__ void k_elite_mean(const float *__restrict__ rows, const int32_t *__restrict__ alias_first, int k, int P,
+                             float *__restrict__ mean)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    float acc = rows[p];
+    for (int j = 1; j < k; ++j) {
+        const float other = (alias_first && alias_first[j]) ? acc : rows[(size_t)j * P + p];
+        acc = acc + other;                       // offspring_strategies.py:245  mu_param += elite_param
+    }
+    mean[p] = acc / (float)k;                    // :248  param /= self.elite_num
+}
+
+__global__ void k_gather_rows(const float *__restrict__ src, const int32_t *__restrict__ ids, int n_ids, int P,
+                              float *__restrict__ dst)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n_ids * P) return;
+    const int i = (int)(t / P);
+    const int p = (int)(t - (long long)i * P);
+    dst[t] = src[(size_t)ids[i] * P + p];
+}
+
+}  // namespace ses
+
+extern "C" {
+
+using namespace ses;
+
+int ses_perturb(ses_handle *h, const float *parents, const int32_t *parent_idx, const int32_t *row_ids, float sigma,
+                uint64_t seed, uint64_t gen, int64_t first_row, int32_t n_rows, float *theta)
+{
+    SES_REQUIRE(h && parents && theta, "ses_perturb: null argument");
+    SES_REQUIRE(n_rows >= 1 && first_row >= 0 && first_row + n_rows <= (1ll << 30), "ses_perturb: row range");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    const int quads = (h->P + 3) / 4;
+    const long long threads = (long long)n_rows * quads;
+    hipLaunchKernelGGL(k_perturb, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, parents, parent_idx, row_ids,
+                       sigma, seed, gen, (long long)first_row, n_rows, h->P, quads, theta);
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+int ses_noise(ses_handle *h, uint64_t seed, uint64_t gen, int64_t first_row, int32_t n_rows, float *eps)
+{
+    SES_REQUIRE(h && eps, "ses_noise: null argument");
+    SES_REQUIRE(n_rows >= 1 && first_row >= 0 && first_row + n_rows <= (1ll << 30), "ses_noise: row range");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    const int quads = (h->P + 3) / 4;
+    const long long threads = (long long)n_rows * quads;
+    hipLaunchKernelGGL(k_noise, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, seed, gen, (long long)first_row,
+                       n_rows, h->P, quads, eps);
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+int ses_perturb_host_noise(ses_handle *h, const float *parents, const int32_t *parent_idx, const double *eps64,
+                           double sigma, int32_t n_rows, float *theta, float *eps_store)
+{
+    SES_REQUIRE(h && parents && eps64 && theta, "ses_perturb_host_noise: null argument");
+    SES_REQUIRE(n_rows >= 1, "ses_perturb_host_noise: n_rows must be >= 1");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    const long long threads = (long long)n_rows * h->P;
+    hipLaunchKernelGGL(k_perturb_host_noise, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, parents,
+                       parent_idx, eps64, sigma, n_rows, h->P, theta, eps_store);
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+int ses_init_states_uniform(ses_handle *h, uint64_t seed, uint64_t gen, int64_t first_row, int32_t n_rows,
+                            int32_t shared, float lo, float hi, float *out)
+{
+    SES_REQUIRE(h && out, "ses_init_states_uniform: null argument");
+    SES_REQUIRE(n_rows >= 1 && first_row >= 0, "ses_init_states_uniform: row range");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    const int S = h->cfg.num_state, E = h->cfg.eval_ep_num;
+    SES_REQUIRE(E * 8 < (1 << 30) && S <= 32, "ses_init_states_uniform: shape");
+    const long long threads = (long long)n_rows * E * ((S + 3) / 4);
+    hipLaunchKernelGGL(k_init_states_uniform, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, seed, gen,
+                       (long long)first_row, n_rows, E, S, shared, lo, hi - lo, out);
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+int ses_rank_center(ses_handle *h, const float *fitness, int32_t n, int32_t *rank, double *weights)
+{
+    SES_REQUIRE(h && fitness && rank, "ses_rank_center: null argument");
+    SES_REQUIRE(n >= 2, "ses_rank_center: need at least 2 offspring (the reference divides by n-1)");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_rank_center, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, fitness, n, rank, weights);
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+int ses_es_update_philox(ses_handle *h, const double *weights, int32_t n, int32_t skip_row0, uint64_t seed,
+                         uint64_t gen, double lr, double sigma, double adam_a, float *mu, float *m, float *v,
+                         float *grad_out)
+{
+    SES_REQUIRE(h && weights && mu && m && v, "ses_es_update_philox: null argument");
+    SES_REQUIRE(n >= 1 && sigma != 0.0, "ses_es_update_philox: bad n / sigma");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    // offspring_strategies.py:406-408: python-float factor, applied to a float32 array (weak scalar -> f32)
+    double uf = lr / ((double)n * sigma);
+    uf *= -1.0;
+    const int quads = (h->P + 3) / 4;
+    hipLaunchKernelGGL(k_es_update_philox, dim3(quads), dim3(256), 0, h->stream, weights, n, skip_row0, seed, gen, h->P,
+                       (float)uf, adam_a, mu, m, v, grad_out);
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+int ses_es_update_stored(ses_handle *h, const double *weights, int32_t n, const float *eps_store, double lr,
+                         double sigma, double adam_a, float *mu, float *m, float *v, float *grad_out)
+{
+    SES_REQUIRE(h && weights && eps_store && mu && m && v, "ses_es_update_stored: null argument");
+    SES_REQUIRE(n >= 1 && sigma != 0.0, "ses_es_update_stored: bad n / sigma");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    double uf = lr / ((double)n * sigma);
+    uf *= -1.0;
+    hipLaunchKernelGGL(k_es_update_stored, dim3(ceil_div(h->P, 64)), dim3(64), 0, h->stream, weights, n, eps_store,
+                       h->P, (float)uf, adam_a, mu, m, v, grad_out);
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+int ses_elite_ids(ses_handle *h, const int32_t *rank, int32_t n, int32_t k, int32_t *elite_ids)
+{
+    SES_REQUIRE(h && rank && elite_ids, "ses_elite_ids: null argument");
+    SES_REQUIRE(n >= 1 && k >= 1 && k <= n, "ses_elite_ids: need 1 <= k <= n");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_elite_ids, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, rank, n, k, elite_ids);
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+int ses_elite_mean(ses_handle *h, const float *rows, const int32_t *alias_first, int32_t k, float *mean)
+{
+    SES_REQUIRE(h && rows && mean, "ses_elite_mean: null argument");
+    SES_REQUIRE(k >= 1, "ses_elite_mean: k must be >= 1");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_elite_mean, dim3(ceil_div(h->P, 256)), dim3(256), 0, h->stream, rows, alias_first, k, h->P,
+                       mean);
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+int ses_gather_rows(ses_handle *h, const float *src, const int32_t *ids, int32_t n_ids, float *dst)
+{
+    SES_REQUIRE(h && src && ids && dst, "ses_gather_rows: null argument");
+    SES_REQUIRE(n_ids >= 1, "ses_gather_rows: n_ids must be >= 1");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    const long long threads = (long long)n_ids * h->P;
+    hipLaunchKernelGGL(k_gather_rows, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, src, ids, n_ids, h->P,
+                       dst);
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+}  // extern "C"

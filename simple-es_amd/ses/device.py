@@ -1,0 +1,235 @@
+"""HipES: shape/dtype-checked torch-tensor front end of the C ABI (include/ses.h).
+
+PyTorch-ROCm tensors are only the parameter/fitness containers; every compute step is a
+hand-written gfx950 kernel inside libses_hip.so, enqueued on torch's current HIP stream.
+All checks happen on the host BEFORE a kernel is launched: a wrong shape raises here, it never
+reaches the GPU.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ENV_CARTPOLE, ENV_NONE, HIDDEN, MODE_EPISODIC, SesConfig, SesError, check
+
+ENV_IDS = {"CartPole-v1": ENV_CARTPOLE, "CartPole-v0": ENV_CARTPOLE, None: ENV_NONE}
+
+
+def param_count(num_state, num_action, gru):
+    return _lib.load().ses_param_count(int(num_state), int(num_action), int(bool(gru)))
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class HipES:
+    """One handle = one (env, network shape, device, stream).  Mirrors the constructor arguments of
+    the reference's builder.build_env / build_network (builder.py:10-24)."""
+
+    def __init__(self, env_name="CartPole-v1", num_state=4, num_action=2, discrete_action=True, gru=False,
+                 pomdp=False, max_step=500, eval_ep_num=5, device=0, lanes_per_env=0):
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise SesError("no HIP device visible to torch: the simple-es hot path needs an MI355X "
+                           "(there is no CPU fallback)")
+        if env_name not in ENV_IDS:
+            raise SesError(f"env {env_name!r} has no device kernel (available: {sorted(k for k in ENV_IDS if k)})")
+        self.device = torch.device("cuda", int(device))
+        self.S, self.A = int(num_state), int(num_action)
+        self.discrete, self.gru, self.pomdp = bool(discrete_action), bool(gru), bool(pomdp)
+        self.max_step, self.E = int(max_step), int(eval_ep_num)
+        self.P = param_count(self.S, self.A, self.gru)
+        self.env_id = ENV_IDS[env_name]
+        cfg = SesConfig(self.env_id, self.S, self.A, int(self.discrete), int(self.gru), int(self.pomdp),
+                        self.max_step, self.E, int(device), int(lanes_per_env))
+        self._lib = lib
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.current_stream(self.device)
+            check(lib.ses_create(ctypes.byref(cfg), ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(self._h)),
+                  "ses_create")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.ses_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- argument validation ------------------------------------------------------------------
+    def _chk(self, t, name, dtype, shape, optional=False):
+        if t is None:
+            if optional:
+                return None
+            raise SesError(f"{name}: tensor required")
+        if not isinstance(t, torch.Tensor):
+            raise SesError(f"{name}: expected a torch tensor, got {type(t).__name__}")
+        if t.device != self.device:
+            raise SesError(f"{name}: on {t.device}, handle is on {self.device}")
+        if t.dtype != dtype:
+            raise SesError(f"{name}: dtype {t.dtype}, expected {dtype}")
+        if not t.is_contiguous():
+            raise SesError(f"{name}: must be contiguous")
+        if tuple(t.shape) != tuple(shape):
+            raise SesError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+        return t
+
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def zeros(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def sync(self):
+        check(self._lib.ses_sync(self._h), "ses_sync")
+
+    # -- K1 -----------------------------------------------------------------------------------
+    def perturb(self, parents, sigma, seed, gen, first_row, n_rows, parent_idx=None, row_ids=None, out=None):
+        parents = parents.view(-1, self.P) if parents.dim() == 1 else parents
+        K = parents.shape[0]
+        self._chk(parents, "parents", torch.float32, (K, self.P))
+        self._chk(parent_idx, "parent_idx", torch.int32, (n_rows,), optional=True)
+        self._chk(row_ids, "row_ids", torch.int32, (n_rows,), optional=True)
+        if parent_idx is not None:
+            lo, hi = int(parent_idx.min()), int(parent_idx.max())
+            if hi >= K or lo < -K:
+                raise SesError(f"parent_idx outside [-{K}, {K})")
+        theta = self.empty(n_rows, self.P) if out is None else self._chk(out, "theta", torch.float32, (n_rows, self.P))
+        check(self._lib.ses_perturb(self._h, _ptr(parents), _ptr(parent_idx), _ptr(row_ids), float(sigma), int(seed),
+                                    int(gen), int(first_row), int(n_rows), _ptr(theta)), "ses_perturb")
+        return theta
+
+    def noise(self, seed, gen, first_row, n_rows):
+        eps = self.empty(n_rows, self.P)
+        check(self._lib.ses_noise(self._h, int(seed), int(gen), int(first_row), int(n_rows), _ptr(eps)), "ses_noise")
+        return eps
+
+    def perturb_host_noise(self, parents, eps64, sigma, parent_idx=None, want_eps_store=False):
+        parents = parents.view(-1, self.P) if parents.dim() == 1 else parents
+        K = parents.shape[0]
+        n_rows = eps64.shape[0]
+        self._chk(parents, "parents", torch.float32, (K, self.P))
+        self._chk(eps64, "eps64", torch.float64, (n_rows, self.P))
+        self._chk(parent_idx, "parent_idx", torch.int32, (n_rows,), optional=True)
+        if parent_idx is not None:
+            lo, hi = int(parent_idx.min()), int(parent_idx.max())
+            if hi >= K or lo < -K:
+                raise SesError(f"parent_idx outside [-{K}, {K})")
+        theta = self.empty(n_rows, self.P)
+        store = self.empty(n_rows, self.P) if want_eps_store else None
+        check(self._lib.ses_perturb_host_noise(self._h, _ptr(parents), _ptr(parent_idx), _ptr(eps64), float(sigma),
+                                               int(n_rows), _ptr(theta), _ptr(store)), "ses_perturb_host_noise")
+        return (theta, store) if want_eps_store else theta
+
+    def init_states_uniform(self, seed, gen, first_row, n_rows, shared=False, lo=-0.05, hi=0.05):
+        out = self.empty(n_rows, self.E, self.S)
+        check(self._lib.ses_init_states_uniform(self._h, int(seed), int(gen), int(first_row), int(n_rows),
+                                                int(bool(shared)), float(lo), float(hi), _ptr(out)),
+              "ses_init_states_uniform")
+        return out
+
+    # -- K2 / K3 ------------------------------------------------------------------------------
+    def policy_forward(self, theta, obs, hidden=None):
+        n = obs.shape[0]
+        self._chk(theta, "theta", torch.float32, (n, self.P))
+        self._chk(obs, "obs", torch.float32, (n, self.S))
+        if self.gru:
+            self._chk(hidden, "hidden", torch.float32, (n, HIDDEN))
+        logits = self.empty(n, self.A)
+        act = self.empty(n, self.A)
+        action = self.empty(n, dtype=torch.int32)
+        check(self._lib.ses_policy_forward(self._h, _ptr(theta), _ptr(obs), _ptr(hidden if self.gru else None), int(n),
+                                           _ptr(logits), _ptr(act), _ptr(action)), "ses_policy_forward")
+        return action, logits, act
+
+    def env_step(self, x, xd, th, thd, action, ret, status, mode=MODE_EPISODIC):
+        n = x.shape[0]
+        for name, t in (("x", x), ("xd", xd), ("th", th), ("thd", thd), ("ret", ret)):
+            self._chk(t, name, torch.float32, (n,))
+        self._chk(action, "action", torch.int32, (n,))
+        self._chk(status, "status", torch.int32, (n,))   # bit pattern of the uint32 status word
+        check(self._lib.ses_env_step(self._h, int(n), int(mode), _ptr(x), _ptr(xd), _ptr(th), _ptr(thd), _ptr(action),
+                                     _ptr(ret), _ptr(status)), "ses_env_step")
+
+    # -- fused rollout ------------------------------------------------------------------------
+    def rollout(self, theta, init, mode=MODE_EPISODIC, want_episodes=False, fitness=None):
+        n_rows = theta.shape[0]
+        self._chk(theta, "theta", torch.float32, (n_rows, self.P))
+        if init.dim() == 2:
+            self._chk(init, "init", torch.float32, (self.E, self.S))
+            per = 0
+        else:
+            self._chk(init, "init", torch.float32, (n_rows, self.E, self.S))
+            per = 1
+        fitness = self.empty(n_rows) if fitness is None else self._chk(fitness, "fitness", torch.float32, (n_rows,))
+        ep_ret = self.empty(n_rows, self.E, dtype=torch.float64) if want_episodes else None
+        ep_steps = self.empty(n_rows, self.E, dtype=torch.int32) if want_episodes else None
+        check(self._lib.ses_rollout(self._h, _ptr(theta), _ptr(init), per, int(n_rows), int(mode), _ptr(fitness),
+                                    _ptr(ep_ret), _ptr(ep_steps)), "ses_rollout")
+        return (fitness, ep_ret, ep_steps) if want_episodes else fitness
+
+    # -- K4 / K5 / K6 -------------------------------------------------------------------------
+    def rank_center(self, fitness):
+        n = fitness.shape[0]
+        self._chk(fitness, "fitness", torch.float32, (n,))
+        rank = self.empty(n, dtype=torch.int32)
+        weights = self.empty(n, dtype=torch.float64)
+        check(self._lib.ses_rank_center(self._h, _ptr(fitness), int(n), _ptr(rank), _ptr(weights)), "ses_rank_center")
+        return rank, weights
+
+    def es_update_philox(self, weights, seed, gen, lr, sigma, adam_a, mu, m, v, skip_row0=True, want_grad=False):
+        n = weights.shape[0]
+        self._chk(weights, "weights", torch.float64, (n,))
+        for name, t in (("mu", mu), ("m", m), ("v", v)):
+            self._chk(t, name, torch.float32, (self.P,))
+        grad = self.empty(self.P) if want_grad else None
+        check(self._lib.ses_es_update_philox(self._h, _ptr(weights), int(n), int(bool(skip_row0)), int(seed), int(gen),
+                                             float(lr), float(sigma), float(adam_a), _ptr(mu), _ptr(m), _ptr(v),
+                                             _ptr(grad)), "ses_es_update_philox")
+        return grad
+
+    def es_update_stored(self, weights, eps_store, lr, sigma, adam_a, mu, m, v, want_grad=False):
+        n = weights.shape[0]
+        self._chk(weights, "weights", torch.float64, (n,))
+        self._chk(eps_store, "eps_store", torch.float32, (n, self.P))
+        for name, t in (("mu", mu), ("m", m), ("v", v)):
+            self._chk(t, name, torch.float32, (self.P,))
+        grad = self.empty(self.P) if want_grad else None
+        check(self._lib.ses_es_update_stored(self._h, _ptr(weights), int(n), _ptr(eps_store), float(lr), float(sigma),
+                                             float(adam_a), _ptr(mu), _ptr(m), _ptr(v), _ptr(grad)),
+              "ses_es_update_stored")
+        return grad
+
+    def elite_ids(self, rank, k):
+        n = rank.shape[0]
+        self._chk(rank, "rank", torch.int32, (n,))
+        if not 1 <= k <= n:
+            raise SesError(f"elite_ids: need 1 <= k <= n, got k={k} n={n}")
+        ids = self.empty(k, dtype=torch.int32)
+        check(self._lib.ses_elite_ids(self._h, _ptr(rank), int(n), int(k), _ptr(ids)), "ses_elite_ids")
+        return ids
+
+    def elite_mean(self, rows, alias_first=None):
+        k = rows.shape[0]
+        self._chk(rows, "rows", torch.float32, (k, self.P))
+        self._chk(alias_first, "alias_first", torch.int32, (k,), optional=True)
+        mean = self.empty(self.P)
+        check(self._lib.ses_elite_mean(self._h, _ptr(rows), _ptr(alias_first), int(k), _ptr(mean)), "ses_elite_mean")
+        return mean
+
+    def gather_rows(self, src, ids):
+        n_src = src.shape[0]
+        k = ids.shape[0]
+        self._chk(src, "src", torch.float32, (n_src, self.P))
+        self._chk(ids, "ids", torch.int32, (k,))
+        lo, hi = int(ids.min()), int(ids.max())
+        if lo < 0 or hi >= n_src:
+            raise SesError(f"gather_rows: ids outside [0, {n_src})")
+        dst = self.empty(k, self.P)
+        check(self._lib.ses_gather_rows(self._h, _ptr(src), _ptr(ids), int(k), _ptr(dst)), "ses_gather_rows")
+        return dst
