@@ -53,22 +53,24 @@ def env_step_roofline(es, n_env, launches=20):
     """Average duration of k_env_step_cartpole over `launches` launches, HIP events on the launch stream."""
     from ses import MODE_FIXED_LENGTH
     g = torch.Generator(device="cuda").manual_seed(0)
-    st = [(torch.rand(n_env, device="cuda", generator=g) - 0.5) * 0.1 for _ in range(4)]
-    action = (torch.rand(n_env, device="cuda", generator=g) > 0.5).to(torch.int32)
-    ret = torch.zeros(n_env, device="cuda")
-    status = torch.zeros(n_env, dtype=torch.int32, device="cuda")
+    x, xd, th, thd, action, ret, status = es.alloc_env_soa(n_env)
+    for t in (x, xd, th, thd):
+        t.copy_((torch.rand(n_env, device="cuda", generator=g) - 0.5) * 0.1)
+    action.copy_((torch.rand(n_env, device="cuda", generator=g) > 0.5).to(torch.int32))
+    st = [x, xd, th, thd]
     for _ in range(3):
         es.env_step(*st, action, ret, status, mode=MODE_FIXED_LENGTH)
     torch.cuda.synchronize()
-    durs = []
+    # `launches` back-to-back launches between two HIP events on the launch stream (torch's current stream
+    # IS the handle's stream): the queue never drains, so the quotient is the kernel's own duration
+    # (cross-checked against rocprofv3 --kernel-trace in profiles/).
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(launches):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()                                   # torch's current stream IS the handle's stream
         es.env_step(*st, action, ret, status, mode=MODE_FIXED_LENGTH)
-        e1.record()
-        e1.synchronize()
-        durs.append(e0.elapsed_time(e1) * 1e-3)
-    avg = sum(durs) / len(durs)
+    e1.record()
+    e1.synchronize()
+    avg = e0.elapsed_time(e1) * 1e-3 / launches
     achieved = BYTES_PER_ENV_STEP * n_env / avg / 1e9
     return {"bound": "hbm", "kernel": "k_env_step_cartpole_v4", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -20,7 +20,7 @@ HIDDEN = 32
 
 def build(force=False):
     """Compile the C restatement with the recipe in oracle/Makefile."""
-    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ses_oracle.c", "ses_oracle_math.h"))
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ses_oracle.c", "ses_oracle_math.h", "ses_tanh_table.h"))
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m:
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _SO

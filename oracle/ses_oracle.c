@@ -282,11 +282,10 @@ void o_policy_forward(int S, int A, int discrete, int gru, int n, const float *t
  * (euler integrator; positions advance with the OLD velocities).              */
 
 #define CP_GRAVITY 9.8f
-#define CP_MASSPOLE 0.1f
-#define CP_TOTAL_MASS 1.1f         /* masspole + masscart (0.1f + 1.0f rounds to this) */
-#define CP_LENGTH 0.5f
-#define CP_POLEMASS_LENGTH 0.05f   /* masspole * length */
-#define CP_FORCE_MAG 10.0f
+#define CP_FORCE_OVER_MASS 0x1.22e8bap+3f   /* force_mag / total_mass   = 10 / 1.1             */
+#define CP_PML_OVER_MASS 0x1.745d18p-5f     /* polemass_length / total_mass = 0.05 / 1.1        */
+#define CP_DEN_C0 0x1.555556p-1f            /* length * 4/3             = 0.5 * 4/3             */
+#define CP_DEN_C1 -0x1.745d18p-5f           /* -length * masspole / total_mass = -0.5*0.1/1.1   */
 #define CP_TAU 0.02f
 #define CP_X_LIMIT 2.4f
 #define CP_THETA_LIMIT 0.20943951f /* 12 deg in rad, f32(12*2*pi/360) */
@@ -294,17 +293,21 @@ void o_policy_forward(int S, int A, int discrete, int gru, int n, const float *t
 
 static inline float clampf(float v, float lim) { return o_minf(o_maxf(v, -lim), lim); }
 
-/* returns 1 when the NEW state is terminal */
+/* returns 1 when the NEW state is terminal.
+ *   temp     = (F + pml*thd^2*sin) / M            with the constant divisions folded into multipliers
+ *   thetaacc = (g*sin - cos*temp) / (l*(4/3 - mp*cos^2/M))
+ *   xacc     = temp - pml*thetaacc*cos / M                                                        */
 static int cartpole_step(float st[4], int action)
 {
     const float x = st[0], xd = st[1], th = st[2], thd = st[3];
-    const float force = action == 1 ? CP_FORCE_MAG : -CP_FORCE_MAG;
+    const float fom = action == 1 ? CP_FORCE_OVER_MASS : -CP_FORCE_OVER_MASS;
     float s, c;
     o_sincosf(th, &s, &c);
-    const float temp = (force + (CP_POLEMASS_LENGTH * (thd * thd)) * s) / CP_TOTAL_MASS;
-    const float thacc = (CP_GRAVITY * s - c * temp) /
-                        (CP_LENGTH * ((4.0f / 3.0f) - (CP_MASSPOLE * (c * c)) / CP_TOTAL_MASS));
-    const float xacc = temp - ((CP_POLEMASS_LENGTH * thacc) * c) / CP_TOTAL_MASS;
+    const float temp = o_fma(CP_PML_OVER_MASS * (thd * thd), s, fom);
+    const float num = o_fma(-c, temp, CP_GRAVITY * s);
+    const float den = o_fma(CP_DEN_C1, c * c, CP_DEN_C0);
+    const float thacc = num / den;
+    const float xacc = o_fma(-CP_PML_OVER_MASS * thacc, c, temp);
     st[0] = clampf(o_fma(CP_TAU, xd, x), CP_CLAMP);
     st[1] = clampf(o_fma(CP_TAU, xacc, xd), CP_CLAMP);
     st[2] = clampf(o_fma(CP_TAU, thd, th), CP_CLAMP);

@@ -12,8 +12,8 @@
  * is to pin every rounding.
  *
  * Accuracy (measured by tests/test_oracle_math.py against float64 libm):
- *   o_expf <= 1 ulp on [-86, 88]; o_tanhf <= 2.5 ulp; o_sigmoidf <= 2 ulp;
- *   o_sincosf <= 1.5 ulp for |x| <= 8192; o_logf <= 1 ulp on (0, 1].
+ *   o_expf <= 1 ulp on [-86, 88]; |o_tanhf - tanh| <= 1.2e-7; |o_sigmoidf - sigmoid| <= 1.2e-7;
+ *   |o_sincosf - sin/cos| <= 1e-7 for |x| <= 8192; o_logf <= 1 ulp on (0, 1].
  * Polynomial coefficients are the classic single-precision Cephes minimax
  * sets (public domain, S. Moshier) -- they are data, re-used here.
  *
@@ -25,6 +25,8 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+
+#include "ses_tanh_table.h"
 
 static inline float o_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
@@ -55,28 +57,24 @@ static inline float o_expf(float x)
     return o_u2f(o_f2u(e) + ((uint32_t)ki << 23));
 }
 
-/* tanh: odd polynomial below 0.625, 1 - 2/(e^{2|x|}+1) above. */
+/* tanh: piecewise cubic on [0, 10) from the generated table (oracle/ses_tanh_table.h, DATA shared with
+ * the device build), odd extension, 1.0 beyond.  d = ax - i/32 is exact in fp32. */
 static inline float o_tanhf(float x)
 {
-    const float ax = fabsf(x);
-    const float z = x * x;
-    float p = -5.70498872745e-3f;
-    p = o_fma(p, z, 2.06390887954e-2f);
-    p = o_fma(p, z, -5.37397155531e-2f);
-    p = o_fma(p, z, 1.33314422036e-1f);
-    p = o_fma(p, z, -3.33332819422e-1f);
-    const float small = o_fma(p * z, x, x);
-    const float t = o_expf(2.0f * o_minf(ax, 10.0f));
-    float big = 1.0f - 2.0f / (t + 1.0f);
-    big = copysignf(big, x);
-    return ax < 0.625f ? small : big;
+    const float ax = o_minf(fabsf(x), SES_TANH_XMAX);
+    const int32_t i = (int32_t)(ax * SES_TANH_H_INV);          /* truncation; ax*32 is exact */
+    const float d = o_fma((float)i, -SES_TANH_H, ax);
+    const float *c = SES_TANH_TABLE[i];
+    float p = o_fma(c[3], d, c[2]);
+    p = o_fma(p, d, c[1]);
+    p = o_fma(p, d, c[0]);
+    return copysignf(p, x);
 }
 
-/* logistic sigmoid 1/(1+e^-x) (torch.sigmoid semantics inside nn.GRU). */
+/* logistic sigmoid (torch.sigmoid inside nn.GRU) = 0.5 + 0.5*tanh(x/2) */
 static inline float o_sigmoidf(float x)
 {
-    const float t = o_expf(-x);
-    return 1.0f / (1.0f + t);
+    return o_fma(0.5f, o_tanhf(0.5f * x), 0.5f);
 }
 
 /* sin and cos together; Cody-Waite reduction by pi/2, valid to |x| ~ 8192,

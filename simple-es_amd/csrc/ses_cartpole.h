@@ -10,11 +10,10 @@
 namespace ses {
 
 constexpr float CP_GRAVITY = 9.8f;
-constexpr float CP_MASSPOLE = 0.1f;
-constexpr float CP_TOTAL_MASS = 1.1f;
-constexpr float CP_LENGTH = 0.5f;
-constexpr float CP_POLEMASS_LENGTH = 0.05f;
-constexpr float CP_FORCE_MAG = 10.0f;
+constexpr float CP_FORCE_OVER_MASS = 0x1.22e8bap+3f;  // force_mag / total_mass = 10 / 1.1
+constexpr float CP_PML_OVER_MASS = 0x1.745d18p-5f;    // polemass_length / total_mass = 0.05 / 1.1
+constexpr float CP_DEN_C0 = 0x1.555556p-1f;           // length * 4/3
+constexpr float CP_DEN_C1 = -0x1.745d18p-5f;          // -length * masspole / total_mass
 constexpr float CP_TAU = 0.02f;
 constexpr float CP_X_LIMIT = 2.4f;
 constexpr float CP_THETA_LIMIT = 0.20943951f;  // 12 degrees
@@ -29,13 +28,16 @@ SES_DEV float clamp_sym(float v, float lim) { return min_(max_(v, -lim), lim); }
 // advances s in place; returns true when the NEW state is terminal
 SES_DEV bool cartpole_step(CartPoleState &s, int action)
 {
-    const float force = action == 1 ? CP_FORCE_MAG : -CP_FORCE_MAG;
+    const float fom = action == 1 ? CP_FORCE_OVER_MASS : -CP_FORCE_OVER_MASS;
     float sn, cs;
     sincos_(s.th, sn, cs);
-    const float temp = (force + (CP_POLEMASS_LENGTH * (s.thd * s.thd)) * sn) / CP_TOTAL_MASS;
-    const float thacc = (CP_GRAVITY * sn - cs * temp) /
-                        (CP_LENGTH * ((4.0f / 3.0f) - (CP_MASSPOLE * (cs * cs)) / CP_TOTAL_MASS));
-    const float xacc = temp - ((CP_POLEMASS_LENGTH * thacc) * cs) / CP_TOTAL_MASS;
+    // temp = (F + pml*thd^2*sin)/M ; thetaacc = (g*sin - cos*temp) / (l*(4/3 - mp*cos^2/M)) ;
+    // xacc = temp - pml*thetaacc*cos/M   -- constant divisions folded into multipliers, one true division
+    const float temp = fma_(CP_PML_OVER_MASS * (s.thd * s.thd), sn, fom);
+    const float num = fma_(-cs, temp, CP_GRAVITY * sn);
+    const float den = fma_(CP_DEN_C1, cs * cs, CP_DEN_C0);
+    const float thacc = num / den;
+    const float xacc = fma_(-CP_PML_OVER_MASS * thacc, cs, temp);
     const float nx = clamp_sym(fma_(CP_TAU, s.xd, s.x), CP_CLAMP);
     const float nxd = clamp_sym(fma_(CP_TAU, xacc, s.xd), CP_CLAMP);
     const float nth = clamp_sym(fma_(CP_TAU, s.thd, s.th), CP_CLAMP);

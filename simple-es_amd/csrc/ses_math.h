@@ -18,6 +18,11 @@
 #define SES_DEV static inline  // host compile of the device functions (tests/hostcheck only)
 #endif
 
+#if defined(__HIPCC__)
+#define SES_TANH_TABLE_QUAL static __device__ const __attribute__((aligned(16)))
+#endif
+#include "ses_tanh_table.h"
+
 namespace ses {
 
 SES_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -47,26 +52,29 @@ SES_DEV float exp_(float x)
     return u2f(f2u(e) + ((uint32_t)ki << 23));
 }
 
-SES_DEV float tanh_(float x)
+// 16-byte table entry: c0 + d*(c1 + d*(c2 + d*c3)) on [i/32, (i+1)/32)
+struct alignas(16) TanhEntry {
+    float c0, c1, c2, c3;
+};
+
+// tanh from the piecewise-cubic table (tools/gen_tanh_table.py); `tab` lives in LDS inside kernels.
+// 11 plain VALU instructions + one ds_read_b128, no division, no transcendental unit.
+SES_DEV float tanh_(const TanhEntry *tab, float x)
 {
-    const float ax = __builtin_fabsf(x);
-    const float z = x * x;
-    float p = -5.70498872745e-3f;
-    p = fma_(p, z, 2.06390887954e-2f);
-    p = fma_(p, z, -5.37397155531e-2f);
-    p = fma_(p, z, 1.33314422036e-1f);
-    p = fma_(p, z, -3.33332819422e-1f);
-    const float small = fma_(p * z, x, x);
-    const float t = exp_(2.0f * min_(ax, 10.0f));
-    float big = 1.0f - 2.0f / (t + 1.0f);
-    big = __builtin_copysignf(big, x);
-    return ax < 0.625f ? small : big;
+    const float ax = min_(__builtin_fabsf(x), SES_TANH_XMAX);
+    const int32_t i = (int32_t)(ax * SES_TANH_H_INV);
+    const float d = fma_((float)i, -SES_TANH_H, ax);  // exact
+    const TanhEntry c = tab[i];
+    float p = fma_(c.c3, d, c.c2);
+    p = fma_(p, d, c.c1);
+    p = fma_(p, d, c.c0);
+    return __builtin_copysignf(p, x);
 }
 
-SES_DEV float sigmoid_(float x)
+// logistic sigmoid = 0.5 + 0.5*tanh(x/2)
+SES_DEV float sigmoid_(const TanhEntry *tab, float x)
 {
-    const float t = exp_(-x);
-    return 1.0f / (1.0f + t);
+    return fma_(0.5f, tanh_(tab, 0.5f * x), 0.5f);
 }
 
 SES_DEV void sincos_(float x, float &s_out, float &c_out)

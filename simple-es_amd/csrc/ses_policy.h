@@ -8,6 +8,7 @@
 //
 // Canonical arithmetic (identical for every LPE, restated by oracle/ses_oracle.c):
 //   fc1  : acc = b1[j]; acc = fma(W1[j][k], obs[k], acc) for k ascending; a[j] = tanh(acc)
+//          (tanh = piecewise-cubic table in LDS, ses_math.h)
 //   fc2  : 8 groups of 4 consecutive hidden units, in-order fma chain from the plain product;
 //          balanced pairwise tree over the 8 group sums; + bias last
 //   argmax: first maximum wins
@@ -75,8 +76,8 @@ struct MlpSlice {
         }
     }
 
-    // obs[S] -> logits[A] (identical in all LPE lanes of the env)
-    __device__ __forceinline__ void forward(const float (&obs)[S], float (&logits)[A]) const
+    // obs[S] -> logits[A] (identical in all LPE lanes of the env); tab: tanh table in LDS
+    __device__ __forceinline__ void forward(const TanhEntry *tab, const float (&obs)[S], float (&logits)[A]) const
     {
         float a[U];
 #pragma unroll
@@ -84,7 +85,7 @@ struct MlpSlice {
             float acc = b1[u];
 #pragma unroll
             for (int k = 0; k < S; ++k) acc = fma_(w1[u][k], obs[k], acc);
-            a[u] = tanh_(acc);
+            a[u] = tanh_(tab, acc);
         }
 #pragma unroll
         for (int o = 0; o < A; ++o) {
@@ -112,6 +113,17 @@ struct MlpSlice {
         }
     }
 };
+
+// cooperative copy of the tanh table into LDS; ends with a workgroup barrier
+__device__ __forceinline__ void stage_tanh_table(TanhEntry *lds)
+{
+    const float4 *src = reinterpret_cast<const float4 *>(&SES_TANH_TABLE[0][0]);
+    for (int i = threadIdx.x; i < SES_TANH_N; i += blockDim.x) {
+        const float4 v = src[i];
+        lds[i] = TanhEntry{v.x, v.y, v.z, v.w};
+    }
+    __syncthreads();
+}
 
 template <int A>
 __device__ __forceinline__ int argmax_first(const float (&logits)[A])

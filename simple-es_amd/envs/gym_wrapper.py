@@ -1,0 +1,83 @@
+"""GymWrapper -- the reference's env adapter (envs/gym_wrapper.py:7-54) backed by the device env kernels.
+
+The reference wraps a gym env object; gym's physics is third-party Python.  Here the env IS a gfx950
+kernel: the population rollout never calls this object step by step (ESLoop hands the whole shard to the
+fused rollout kernel), it only reads `name / max_step / pomdp`.  `reset()` / `step()` keep the reference's
+dict protocol for single-env use (checkpoint playback) and run one-lane launches of ses_env_step.
+"""
+import numpy as np
+import torch
+
+SUPPORTED = {"CartPole-v1": dict(num_state=4, num_action=2, discrete=True, time_limit=500),
+             "CartPole-v0": dict(num_state=4, num_action=2, discrete=True, time_limit=200)}
+
+
+class GymWrapper:
+    def __init__(self, name, max_step=None, pomdp=False):
+        if name not in SUPPORTED:
+            raise NotImplementedError(
+                f"env {name!r} has no gfx950 kernel in this build (available: {sorted(SUPPORTED)}); "
+                "there is no CPU/gym fallback")
+        if pomdp and "CartPole" not in name and "LunarLander" not in name:
+            raise AssertionError(f"{name} doesn't support POMDP.")
+        self.name = name
+        self.pomdp = bool(pomdp)
+        self.spec = SUPPORTED[name]
+        # YAML `max_step: None` is the STRING "None" in the reference (gym_wrapper.py:37); accept both.
+        limit = self.spec["time_limit"]
+        self.max_step = max_step
+        self.horizon = limit if max_step in (None, "None") else min(int(max_step), limit)
+        self.curr_step = 0
+        self.seed_env = 0
+        self._episode = 0
+        self._dev = None
+        self._soa = None
+
+    def get_agent_ids(self):
+        return ["0"]
+
+    # ---- single-env protocol (playback) ---------------------------------------------------------
+    def _device(self):
+        if self._dev is None:
+            from ses import HipES
+            self._dev = HipES(self.name, 4, 2, True, False, pomdp=self.pomdp, max_step=self.horizon, eval_ep_num=1)
+        return self._dev
+
+    def _obs(self):
+        x, xd, th, thd = (float(t[0].item()) for t in self._soa[:4])
+        obs = np.array([x, xd, th, thd], dtype=np.float32)
+        if self.pomdp:
+            obs[1] = 0
+            obs[3] = 0
+        return obs
+
+    def reset(self):
+        dev = self._device()
+        self.curr_step = 0
+        s0 = dev.init_states_uniform(self.seed_env, self._episode, 0, 1)[0, 0]
+        self._episode += 1
+        x, xd, th, thd, action, ret, status = dev.alloc_env_soa(4)      # 4 lanes: one vector group, lane 0 is the env
+        for t, v in zip((x, xd, th, thd), s0):
+            t.fill_(float(v))
+        self._soa = (x, xd, th, thd, action, ret, status)
+        return {"0": {"state": self._obs()}}
+
+    def step(self, action):
+        dev = self._device()
+        self.curr_step += 1
+        x, xd, th, thd, act, ret, status = self._soa
+        act.fill_(int(np.asarray(action["0"])))
+        before = float(ret[0].item())
+        dev.env_step(x, xd, th, thd, act, ret, status)
+        r = float(ret[0].item()) - before
+        d = bool(int(status[0].item()) < 0)                              # bit 31 = done
+        tr = {"state": self._obs(), "reward": r, "done": d, "info": {}}
+        return {"0": tr}, r, d, {}
+
+    def render(self):
+        raise NotImplementedError("no renderer on the device path")
+
+    def close(self):
+        if self._dev is not None:
+            self._dev.close()
+            self._dev = None

@@ -1,0 +1,272 @@
+"""simple_genetic / simple_evolution / openai_es with the reference's constructor signatures and methods
+(learning_strategies/evolution/offspring_strategies.py:11-434), re-designed around a device-resident
+population:
+
+  reference                                    here
+  -----------------------------------------    -----------------------------------------------------------
+  list of N {agent_id: torch module}           Population: float32[N_local, P] on the GPU (+ lazy module view)
+  deepcopy + np.random.normal per offspring    one Philox perturbation kernel over the shard (ses_perturb)
+  python argsort / rank loop / z-score         ses_rank_center (exact counting rank, float64 weights)
+  python sum over N modules + numpy Adam       ses_es_update_* (ES gradient + Adam fused)
+  in-place elite sum over modules              ses_elite_ids / ses_perturb(row_ids) / ses_elite_mean
+
+Population layouts and quirks are kept: openai_es has N members with member 0 = mu;
+simple_evolution has N+1 = [mu, elite0, N-1 children] and its elite "mean" reproduces the reference's
+in-place aliasing; simple_genetic has k*(N//k) members and decays sigma AFTER regenerating.
+
+noise="philox" (default): counter-based device noise; any GPU count gives the same population.
+noise="numpy": the reference's own stream -- float64 draws from the global numpy generator, uploaded and
+applied on the device with the reference's float64->float32 rounding; with the same seed the populations
+and parent updates are bit-identical to the reference (single process only).
+"""
+import numpy as np
+import torch
+
+from learning_strategies.optimizers import Adam
+from ses import HipES
+from ses.parallel import Shard
+
+from .abstracts import BaseOffspringStrategy
+from .utils import wrap_agentid
+
+
+class Population:
+    """The offspring group handed from a strategy to ESLoop.  Device view: `theta` (this rank's rows);
+    sequence view (len / index / iterate) materialises {agent_id: module} dicts like the reference's list."""
+
+    def __init__(self, theta, shard, network, agent_ids, gen):
+        self.theta = theta            # float32[n_local, P] on the device
+        self.shard = shard
+        self.gen = gen                # generation counter (keys the env-init Philox stream in ESLoop)
+        self._network = network
+        self._agent_ids = agent_ids
+
+    def __len__(self):
+        return self.shard.n_global
+
+    def __getitem__(self, i):
+        if not 0 <= i < self.shard.n_global:
+            raise IndexError(i)
+        j = i - self.shard.first
+        if not 0 <= j < self.shard.n_local:
+            raise IndexError(f"offspring {i} lives on another rank")
+        import copy
+        net = copy.deepcopy(self._network).load_flat(self.theta[j].cpu().numpy())
+        return wrap_agentid(self._agent_ids, net)
+
+    def __iter__(self):
+        return (self[i] for i in range(self.shard.first, self.shard.first + self.shard.n_local))
+
+
+class _DeviceStrategy(BaseOffspringStrategy):
+    def __init__(self, init_sigma, sigma_decay, offspring_num, noise, seed):
+        if noise not in ("philox", "numpy"):
+            raise ValueError("noise must be 'philox' or 'numpy'")
+        self.offspring_num = offspring_num
+        self.init_sigma = init_sigma
+        self.sigma_decay = sigma_decay
+        self.curr_sigma = init_sigma
+        self.noise = noise
+        self.seed = int(seed)
+        self.gen = 0                  # bumped by every _gen_offsprings: Philox generation key
+        self.dev = None
+
+    # ---- plumbing -----------------------------------------------------------------------------
+    def _bind(self, network, agent_ids):
+        self.agent_ids = agent_ids
+        self.network = network
+        network.zero_init()           # every strategy starts from the zero network (offspring_strategies.py:83,200,348)
+        self.dev = HipES(None, network.num_state, network.num_action, network.discrete_action, network.use_gru)
+        self.P = self.dev.P
+
+    def _population_size(self):
+        raise NotImplementedError
+
+    def _materialise(self, parents, parent_idx_host, sigma):
+        """Build this rank's rows of the population described by (parents[K,P], parent_idx[N])."""
+        n = len(parent_idx_host)
+        shard = Shard(n)
+        if self.noise == "numpy" and shard.world != 1:
+            raise RuntimeError("noise='numpy' reproduces the reference's single global stream: run it on one process")
+        lo, hi = shard.first, shard.first + shard.n_local
+        idx = torch.from_numpy(np.ascontiguousarray(parent_idx_host[lo:hi], dtype=np.int32)).to(self.dev.device)
+        self._last = {"parents": parents, "idx_host": np.asarray(parent_idx_host, dtype=np.int32), "sigma": sigma,
+                      "gen": self.gen, "shard": shard}
+        if self.noise == "philox":
+            theta = self.dev.perturb(parents, sigma, self.seed, self.gen, lo, shard.n_local, parent_idx=idx)
+        else:
+            eps = np.zeros((n, self.P))
+            for i in range(n):                     # the reference draws only for perturbed members, in order
+                if parent_idx_host[i] >= 0:
+                    eps[i] = np.random.normal(size=self.P)
+            eps64 = torch.from_numpy(eps).to(self.dev.device)
+            theta, store = self.dev.perturb_host_noise(parents, eps64, sigma, parent_idx=idx, want_eps_store=True)
+            self._last["eps_store"] = store
+            self._last["theta"] = theta
+        pop = Population(theta, shard, self.network, self.agent_ids, self.gen)
+        self.gen += 1
+        return pop
+
+    def _rows(self, ids_host):
+        """Parameter rows of the CURRENT population for global ids (any rank can rebuild any row)."""
+        last = self._last
+        ids = np.asarray(ids_host, dtype=np.int32)
+        if self.noise == "numpy":
+            return self.dev.gather_rows(last["theta"], torch.from_numpy(ids).to(self.dev.device))
+        idx = torch.from_numpy(np.ascontiguousarray(last["idx_host"][ids])).to(self.dev.device)
+        rows = torch.from_numpy(ids).to(self.dev.device)
+        return self.dev.perturb(last["parents"], last["sigma"], self.seed, last["gen"], 0, len(ids),
+                                parent_idx=idx, row_ids=rows)
+
+    def _fitness_tensor(self, rewards):
+        if isinstance(rewards, torch.Tensor):
+            fit = rewards.to(device=self.dev.device, dtype=torch.float32).contiguous()
+        else:
+            fit = torch.as_tensor(np.asarray(rewards, dtype=np.float32)).to(self.dev.device)
+        if fit.numel() != self._population_size():
+            raise ValueError(f"expected {self._population_size()} rewards, got {fit.numel()}")
+        return fit
+
+    def _model_from(self, vec):
+        import copy
+        return copy.deepcopy(self.network).load_flat(vec.detach().cpu().numpy())
+
+
+class simple_genetic(_DeviceStrategy):
+    def __init__(self, init_sigma, sigma_decay, elite_num, offspring_num, noise="philox", seed=0):
+        super().__init__(init_sigma, sigma_decay, offspring_num, noise, seed)
+        self.elite_num = elite_num
+        self.elite_models = None      # device float32[k, P], best first
+
+    def _population_size(self):
+        return self.elite_num * (self.offspring_num // self.elite_num)
+
+    def _gen_offsprings(self, agent_ids, elite_models, elite_num, offspring_num, sigma):
+        per = offspring_num // elite_num
+        idx = np.empty(elite_num * per, dtype=np.int32)
+        for e in range(elite_num):
+            idx[e * per] = -1 - e                 # the elite itself, verbatim
+            idx[e * per + 1:(e + 1) * per] = e    # its children
+        return self._materialise(elite_models, idx, sigma)
+
+    def get_elite_model(self):
+        return self._model_from(self.elite_models[0])
+
+    def init_offspring(self, network, agent_ids):
+        self._bind(network, agent_ids)
+        self.elite_models = self.dev.zeros(self.elite_num, self.P)
+        return self._gen_offsprings(agent_ids, self.elite_models, self.elite_num, self.offspring_num, self.curr_sigma)
+
+    def evaluate(self, rewards):
+        fit = self._fitness_tensor(rewards)
+        rank, _ = self.dev.rank_center(fit)
+        best_reward = float(fit.max().item())
+        ids = self.dev.elite_ids(rank, self.elite_num).cpu().numpy()
+        self.elite_ids = ids
+        self.elite_models = self._rows(ids)
+        pop = self._gen_offsprings(self.agent_ids, self.elite_models, self.elite_num, self.offspring_num,
+                                   self.curr_sigma)
+        self.curr_sigma *= self.sigma_decay       # decays AFTER regeneration (offspring_strategies.py:117-124)
+        return pop, best_reward, self.curr_sigma
+
+    def get_wandb_cfg(self):
+        return dict(init_sigma=self.init_sigma, sigma_decay=self.sigma_decay, elite_num=self.elite_num,
+                    offspring_num=self.offspring_num)
+
+
+class simple_evolution(_DeviceStrategy):
+    def __init__(self, init_sigma, sigma_decay, elite_num, offspring_num, noise="philox", seed=0):
+        super().__init__(init_sigma, sigma_decay, offspring_num, noise, seed)
+        self.elite_num = elite_num
+        self.mu_model = None          # device float32[P]
+        self.elite0 = None            # device float32[P]  (elite_models[0])
+        self._slots_alias = True      # population slots 0 and 1 are the same module object
+
+    def _population_size(self):
+        return self.offspring_num + 1
+
+    def _gen_offsprings(self, agent_ids, elite_models, mu_model, sigma, offspring_num):
+        parents = torch.stack([mu_model, elite_models]).contiguous()
+        idx = np.zeros(offspring_num + 1, dtype=np.int32)
+        idx[0], idx[1] = -1, -2                   # [mu, elite0, then N-1 children of mu]
+        return self._materialise(parents, idx, sigma)
+
+    def get_elite_model(self):
+        return self._model_from(self.elite0)
+
+    def init_offspring(self, network, agent_ids):
+        self._bind(network, agent_ids)
+        self.mu_model = self.dev.zeros(self.P)
+        self.elite0 = self.dev.zeros(self.P)
+        self._slots_alias = True
+        return self._gen_offsprings(agent_ids, self.elite0, self.mu_model, self.curr_sigma, self.offspring_num)
+
+    def evaluate(self, rewards):
+        fit = self._fitness_tensor(rewards)
+        rank, _ = self.dev.rank_center(fit)
+        best_reward = float(fit.max().item())
+        ids = self.dev.elite_ids(rank, self.elite_num).cpu().numpy()
+        self.elite_ids = ids
+        rows = self._rows(ids)
+        # the reference sums the elites IN PLACE into elite[0]; an elite that is the same object as elite[0]
+        # (slots 0 and 1 while they alias) doubles the running sum instead of adding its own value
+        alias = np.zeros(self.elite_num, dtype=np.int32)
+        if self._slots_alias and ids[0] in (0, 1):
+            for j in range(1, self.elite_num):
+                if ids[j] in (0, 1) and ids[j] != ids[0]:
+                    alias[j] = 1
+        mean = self.dev.elite_mean(rows, torch.from_numpy(alias).to(self.dev.device) if alias.any() else None)
+        self._slots_alias = bool(ids[0] == 0 or (ids[0] == 1 and self._slots_alias))
+        self.mu_model = mean
+        self.elite0 = mean                         # elite[0] was overwritten with the mean (aliasing quirk)
+        self.curr_sigma *= self.sigma_decay
+        pop = self._gen_offsprings(self.agent_ids, self.elite0, self.mu_model, self.curr_sigma, self.offspring_num)
+        return pop, best_reward, self.curr_sigma
+
+    def get_wandb_cfg(self):
+        return dict(init_sigma=self.init_sigma, elite_num=self.elite_num, offspring_num=self.offspring_num)
+
+
+class openai_es(_DeviceStrategy):
+    def __init__(self, init_sigma, sigma_decay, learning_rate, offspring_num, noise="philox", seed=0):
+        super().__init__(init_sigma, sigma_decay, offspring_num, noise, seed)
+        self.learning_rate = learning_rate
+        self.mu_model = None
+        self.optimizer = None
+
+    def _population_size(self):
+        return self.offspring_num
+
+    def _gen_offsprings(self, agent_ids, mu_model, sigma, offspring_num):
+        idx = np.zeros(offspring_num, dtype=np.int32)
+        idx[0] = -1                               # member 0 is the unperturbed mu (epsilon = 0)
+        return self._materialise(mu_model.view(1, -1), idx, sigma)
+
+    def get_elite_model(self):
+        return self._model_from(self.mu_model)
+
+    def init_offspring(self, network, agent_ids):
+        self._bind(network, agent_ids)
+        self.mu_model = self.dev.zeros(self.P)
+        self.optimizer = Adam(self.mu_model, self.learning_rate)
+        return self._gen_offsprings(agent_ids, self.mu_model, self.curr_sigma, self.offspring_num)
+
+    def evaluate(self, rewards):
+        fit = self._fitness_tensor(rewards)
+        _, weights = self.dev.rank_center(fit)
+        best_reward = float(fit.max().item())
+        a = self.optimizer.next_step_scale()
+        opt = self.optimizer
+        if self.noise == "philox":
+            self.dev.es_update_philox(weights, self.seed, self._last["gen"], self.learning_rate, self.curr_sigma, a,
+                                      self.mu_model, opt.m, opt.v, skip_row0=True)
+        else:
+            self.dev.es_update_stored(weights, self._last["eps_store"], self.learning_rate, self.curr_sigma, a,
+                                      self.mu_model, opt.m, opt.v)
+        self.curr_sigma *= self.sigma_decay
+        pop = self._gen_offsprings(self.agent_ids, self.mu_model, self.curr_sigma, self.offspring_num)
+        return pop, best_reward, self.curr_sigma
+
+    def get_wandb_cfg(self):
+        return dict(init_sigma=self.init_sigma, sigma_decay=self.sigma_decay, learning_rate=self.learning_rate,
+                    offspring_num=self.offspring_num)

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libses_hip.so")
+LIB_PATH = os.environ.get("SES_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libses_hip.so")  # env: dev A/B builds
 
 SES_OK = 0
 ENV_NONE = -1

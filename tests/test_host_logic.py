@@ -1,0 +1,99 @@
+"""CPU tests of the host-side logic: population sharding arithmetic, the world_size-2 fitness all-gather
+over gloo (the N>1 path of bench.py / ESLoop, RCCL on the GPU box), config surface of builder / run_es."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "simple-es_amd")
+
+
+def test_shard_partition_covers_population_exactly():
+    from ses.parallel import Shard
+    import torch.distributed as dist
+    assert not dist.is_initialized()
+    s = Shard(4097)
+    assert (s.world, s.rank, s.first, s.n_local) == (1, 0, 0, 4097)
+    # emulate W ranks without a process group
+    for n in (1, 2, 7, 96, 97, 4096, 65536):
+        for w in (1, 2, 3, 4, 8):
+            per = -(-n // w)
+            rows = []
+            for r in range(w):
+                first = min(r * per, n)
+                rows += list(range(first, first + max(0, min(per, n - first))))
+            assert rows == list(range(n))
+
+
+WORKER = textwrap.dedent("""
+    import sys, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    dist.init_process_group("gloo")
+    from ses.parallel import Shard
+    for n in (10, 7, 1, 2, 4096):
+        sh = Shard(n)
+        local = torch.arange(sh.first, sh.first + sh.n_local, dtype=torch.float32) * 0.5
+        out = sh.allgather_fitness(local)
+        assert out.shape == (n,) and out.tolist() == [0.5 * i for i in range(n)], (n, out)
+        sh.barrier()
+    open(sys.argv[1] + "/rank" + str(dist.get_rank()) + ".ok", "w").write("ok")
+    dist.destroy_process_group()
+""")
+
+
+def test_fitness_allgather_world_size_2_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % SRC)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), str(tmp_path)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
+def test_config_surface_matches_reference_yaml_keys():
+    cfg = yaml.load(open(os.path.join(SRC, "conf", "cartpole.yaml")), Loader=yaml.FullLoader)
+    assert set(cfg) == {"env", "network", "strategy"}
+    assert set(cfg["env"]) == {"name", "max_step", "pomdp"}
+    assert set(cfg["network"]) == {"name", "num_state", "num_action", "discrete_action", "gru"}
+    assert set(cfg["strategy"]) == {"name", "init_sigma", "sigma_decay", "elite_num", "offspring_num"}
+
+
+def test_cli_flags_match_reference():
+    out = subprocess.run([sys.executable, os.path.join(SRC, "run_es.py"), "--help"], capture_output=True, text=True,
+                         cwd=SRC, timeout=120)
+    assert out.returncode == 0, out.stderr
+    for flag in ("--cfg-path", "--seed", "--process-num", "--generation-num", "--eval-ep-num", "--log",
+                 "--save-model-period"):
+        assert flag in out.stdout
+
+
+def test_network_container_layout_and_checkpoint_keys():
+    import numpy as np
+    from networks.neural_network import GymEnvModel
+    m = GymEnvModel(4, 2, True, True)
+    assert list(m.state_dict()) == ["fc1.weight", "fc1.bias", "gru.weight_ih_l0", "gru.weight_hh_l0",
+                                    "gru.bias_ih_l0", "gru.bias_hh_l0", "fc2.weight", "fc2.bias"]
+    assert m.param_count() == 6562
+    vec = np.arange(6562, dtype=np.float32)
+    m.load_flat(vec)
+    assert np.array_equal(m.flat(), vec)
+    assert np.array_equal(m.get_param_list()[0], vec[:128].reshape(32, 4))          # fc1.weight is row-major (32,S)
+    m.zero_init()
+    assert not m.flat().any()
+    views = m.get_param_list()
+    views[1] += 1.0                                                                 # views edit the module in place
+    assert m.fc1.bias.sum().item() == 32.0
+
+
+@pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="needs a box without a GPU")
+def test_strategies_refuse_to_run_without_gpu():
+    from learning_strategies.evolution.offspring_strategies import openai_es
+    from networks.neural_network import GymEnvModel
+    from ses import SesError
+    with pytest.raises(SesError):
+        openai_es(0.1, 0.999, 0.05, 16).init_offspring(GymEnvModel(4, 2, True, False), ["0"])

@@ -63,7 +63,7 @@ def test_g1_forward_matches_reference(g1, ci):
                 assert top[1] - top[0] < 1e-5
             flips += int(bad.sum())
         else:
-            np.testing.assert_allclose(act, g1[f"c{ci}_act"][:, t], rtol=0, atol=3e-6)
+            np.testing.assert_allclose(act, g1[f"c{ci}_act"][:, t], rtol=0, atol=1e-5)   # |dtanh| <= |dlogit|
     assert flips == 0      # no near-ties happen to occur in this fixture
 
 

@@ -1,0 +1,9 @@
+#!/bin/bash
+# rocprofv3 kernel trace of the default bench command; summaries land in gpurun_out/prof_*
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $R/gpurun_out
+rm -rf $R/gpurun_out/prof_kt
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt -- python3 $R/bench.py --no-cpu-baseline "$@" > $R/gpurun_out/prof_kt_bench.log 2>&1
+tail -1 $R/gpurun_out/prof_kt_bench.log
+find $R/gpurun_out/prof_kt -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'cp {} '$R'/gpurun_out/kernel_stats.csv; head -20 {}'
