@@ -202,6 +202,16 @@ static inline float dot_chain(const float *w, const float *x, int n, float acc)
     return acc;
 }
 
+/* GRU gate row (32 inputs): the device splits the reduction over the two halves of a wavefront, so the
+ * canonical order is  (bias + chain over k = 0..15)  +  (0 + chain over k = 16..31). */
+static inline float dot_split16(const float *w, const float *x, float bias)
+{
+    float lo = bias, hi = 0.0f;
+    for (int k = 0; k < 16; ++k) lo = o_fma(w[k], x[k], lo);
+    for (int k = 16; k < 32; ++k) hi = o_fma(w[k], x[k], hi);
+    return lo + hi;
+}
+
 /* fc2 row: 8 groups of 4 consecutive hidden units (in-order chain starting from the plain
  * product), then a balanced pairwise tree over the 8 group sums, then + bias. */
 static inline float fc2_row(const float *w, const float *h, float bias)
@@ -238,12 +248,12 @@ static int policy_forward(const net_view *v, int S, int A, int discrete, int gru
     if (gru) {
         /* torch.nn.GRU cell, gate order r, z, n */
         for (int j = 0; j < SES_H; ++j) {
-            const float gir = dot_chain(v->wih + (0 * SES_H + j) * SES_H, a, SES_H, v->bih[0 * SES_H + j]);
-            const float giz = dot_chain(v->wih + (1 * SES_H + j) * SES_H, a, SES_H, v->bih[1 * SES_H + j]);
-            const float gin = dot_chain(v->wih + (2 * SES_H + j) * SES_H, a, SES_H, v->bih[2 * SES_H + j]);
-            const float ghr = dot_chain(v->whh + (0 * SES_H + j) * SES_H, h, SES_H, v->bhh[0 * SES_H + j]);
-            const float ghz = dot_chain(v->whh + (1 * SES_H + j) * SES_H, h, SES_H, v->bhh[1 * SES_H + j]);
-            const float ghn = dot_chain(v->whh + (2 * SES_H + j) * SES_H, h, SES_H, v->bhh[2 * SES_H + j]);
+            const float gir = dot_split16(v->wih + (0 * SES_H + j) * SES_H, a, v->bih[0 * SES_H + j]);
+            const float giz = dot_split16(v->wih + (1 * SES_H + j) * SES_H, a, v->bih[1 * SES_H + j]);
+            const float gin = dot_split16(v->wih + (2 * SES_H + j) * SES_H, a, v->bih[2 * SES_H + j]);
+            const float ghr = dot_split16(v->whh + (0 * SES_H + j) * SES_H, h, v->bhh[0 * SES_H + j]);
+            const float ghz = dot_split16(v->whh + (1 * SES_H + j) * SES_H, h, v->bhh[1 * SES_H + j]);
+            const float ghn = dot_split16(v->whh + (2 * SES_H + j) * SES_H, h, v->bhh[2 * SES_H + j]);
             const float r = o_sigmoidf(gir + ghr);
             const float z = o_sigmoidf(giz + ghz);
             const float n = o_tanhf(o_fma(r, ghn, gin));

@@ -6,6 +6,7 @@
 #include <cstdlib>
 
 #include "ses_cartpole.h"
+#include "ses_gru.h"
 #include "ses_internal.h"
 #include "ses_policy.h"
 
@@ -72,6 +73,66 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_cartpole_mlp(const float *__r
     if (valid && sub == 0) {
         if (ep_return) ep_return[env] = (double)steps;  // CartPole reward is 1 per step incl. the terminal one
         if (ep_steps) ep_steps[env] = steps;
+    }
+}
+
+// GRU policy: one offspring per wavefront (ses_gru.h), its E episodes run one after the other so the
+// 6 x 16 + ... weights per lane stay in VGPRs across all of them.  4 offspring per 256-thread workgroup
+// share one copy of the tanh table; the waves never synchronise with each other (episode lengths differ).
+template <bool FIXED_LENGTH>
+__global__ __launch_bounds__(256) void k_rollout_cartpole_gru(const float *__restrict__ theta,
+                                                              const float *__restrict__ init, int init_per_offspring,
+                                                              int n_rows, int E, int P, int max_step,
+                                                              uint32_t obs_mask, double *__restrict__ ep_return,
+                                                              int32_t *__restrict__ ep_steps)
+{
+    __shared__ TanhEntry tanh_tab[SES_TANH_N];
+    __shared__ __attribute__((aligned(16))) float vecs[4][64];
+    stage_tanh_table(tanh_tab);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int row = blockIdx.x * 4 + wave;
+    const bool valid = row < n_rows;
+    row = valid ? row : n_rows - 1;
+    GruSlice<4, 2> net;
+    net.load(theta + (size_t)row * P, lane);
+    float *vec = vecs[wave];
+    for (int ep = 0; ep < E; ++ep) {
+        const float *s0 = init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 4;
+        CartPoleState st{s0[0], s0[1], s0[2], s0[3]};
+        float h = 0.0f;                                   // GymEnvModel.reset(), neural_network.py:38-40
+        wave_lds_sync();
+        if (lane < 32) vec[32 + lane] = 0.0f;
+        wave_lds_sync();
+        int steps = 0;
+        bool alive = true;
+        for (int t = 0; t < max_step; ++t) {
+            if constexpr (!FIXED_LENGTH) {
+                if (__builtin_amdgcn_readfirstlane((int)alive) == 0) break;   // one env per wave: uniform
+            }
+            float obs[4];
+            obs[0] = (obs_mask & 1u) ? 0.0f : st.x;
+            obs[1] = (obs_mask & 2u) ? 0.0f : st.xd;
+            obs[2] = (obs_mask & 4u) ? 0.0f : st.th;
+            obs[3] = (obs_mask & 8u) ? 0.0f : st.thd;
+            float logits[2];
+            net.forward(tanh_tab, obs, h, vec, lane, logits);
+            const int action = argmax_first<2>(logits);
+            CartPoleState ns = st;
+            const bool term = cartpole_step(ns, action);
+            const bool advance = FIXED_LENGTH ? true : alive;
+            st.x = advance ? ns.x : st.x;
+            st.xd = advance ? ns.xd : st.xd;
+            st.th = advance ? ns.th : st.th;
+            st.thd = advance ? ns.thd : st.thd;
+            const int nsteps = steps + 1;
+            const bool finished = term | (nsteps >= max_step);
+            steps = alive ? nsteps : steps;
+            alive = alive & !finished;
+        }
+        if (valid && lane == 0) {
+            if (ep_return) ep_return[(size_t)row * E + ep] = (double)steps;
+            if (ep_steps) ep_steps[(size_t)row * E + ep] = steps;
+        }
     }
 }
 
@@ -187,6 +248,44 @@ __global__ __launch_bounds__(64) void k_policy_forward_mlp(const float *__restri
     }
 }
 
+// Standalone GRU forward: one (row, obs, hidden) triple per wavefront.
+template <int S, int A>
+__global__ __launch_bounds__(256) void k_policy_forward_gru(const float *__restrict__ theta,
+                                                            const float *__restrict__ obs_in,
+                                                            float *__restrict__ hidden, int n, int P,
+                                                            float *__restrict__ logits_out, float *__restrict__ act_out,
+                                                            int32_t *__restrict__ action_out)
+{
+    __shared__ TanhEntry tanh_tab[SES_TANH_N];
+    __shared__ __attribute__((aligned(16))) float vecs[4][64];
+    stage_tanh_table(tanh_tab);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int i = blockIdx.x * 4 + wave;
+    const bool valid = i < n;
+    i = valid ? i : n - 1;
+    GruSlice<S, A> net;
+    net.load(theta + (size_t)i * P, lane);
+    float *vec = vecs[wave];
+    float obs[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) obs[k] = obs_in[(size_t)i * S + k];
+    float h = hidden[(size_t)i * H + (lane & 31)];
+    if (lane < 32) vec[32 + lane] = h;
+    wave_lds_sync();
+    float logits[A];
+    net.forward(tanh_tab, obs, h, vec, lane, logits);
+    const int action = argmax_first<A>(logits);
+    if (valid && lane < 32) hidden[(size_t)i * H + lane] = h;
+    if (valid && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            logits_out[(size_t)i * A + k] = logits[k];
+            if (act_out) act_out[(size_t)i * A + k] = tanh_(tanh_tab, logits[k]);
+        }
+        action_out[i] = action;
+    }
+}
+
 static int pick_lanes_per_env(const ses_handle *h, long long n_env)
 {
     if (h->cfg.lanes_per_env) return h->cfg.lanes_per_env;
@@ -236,7 +335,6 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
     SES_REQUIRE(mode == SES_MODE_EPISODIC || mode == SES_MODE_FIXED_LENGTH, "ses_rollout: bad mode %d", mode);
     SES_REQUIRE((long long)n_rows * h->cfg.eval_ep_num * 8 < (1ll << 31), "ses_rollout: shard too large");
     SES_REQUIRE(h->cfg.env_id == SES_ENV_CARTPOLE, "ses_rollout: handle has no env");
-    if (h->cfg.gru) return set_error(SES_ERR_UNSUPPORTED, "ses_rollout: GRU policy kernel not built yet");
     SES_HIP_TRY(hipSetDevice(h->cfg.device));
     const size_t episodes = (size_t)n_rows * h->cfg.eval_ep_num;
     double *epr = ep_return;
@@ -245,6 +343,17 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
         if (rc != SES_OK) return rc;
         epr = h->ep_return;
     }
+    if (h->cfg.gru) {
+        const int blocks = ceil_div(n_rows, 4);
+        if (mode == SES_MODE_FIXED_LENGTH)
+            hipLaunchKernelGGL((k_rollout_cartpole_gru<true>), dim3(blocks), dim3(256), 0, h->stream, theta, init,
+                               init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
+                               epr, ep_steps);
+        else
+            hipLaunchKernelGGL((k_rollout_cartpole_gru<false>), dim3(blocks), dim3(256), 0, h->stream, theta, init,
+                               init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
+                               epr, ep_steps);
+    } else
     switch (pick_lanes_per_env(h, (long long)episodes)) {
         case 1: launch_rollout<1>(h, theta, init, init_per_offspring, n_rows, mode, epr, ep_steps); break;
         case 2: launch_rollout<2>(h, theta, init, init_per_offspring, n_rows, mode, epr, ep_steps); break;
@@ -302,11 +411,24 @@ int ses_policy_forward(ses_handle *h, const float *theta, const float *obs, floa
     using namespace ses;
     SES_REQUIRE(h && theta && obs && logits && action, "ses_policy_forward: null argument");
     SES_REQUIRE(n >= 1 && (long long)n * 4 < (1ll << 31), "ses_policy_forward: n out of range");
-    if (h->cfg.gru) return set_error(SES_ERR_UNSUPPORTED, "ses_policy_forward: GRU policy kernel not built yet");
-    (void)hidden;
     SES_HIP_TRY(hipSetDevice(h->cfg.device));
-    const int blocks = ceil_div((long long)n * 4, 64);
     const int S = h->cfg.num_state, A = h->cfg.num_action;
+    if (h->cfg.gru) {
+        SES_REQUIRE(hidden, "ses_policy_forward: GRU policy needs the hidden-state array");
+        const int gblocks = ceil_div(n, 4);
+#define SES_GRU_CASE(S_, A_)                                                                                      \
+    if (S == S_ && A == A_) {                                                                                     \
+        hipLaunchKernelGGL((k_policy_forward_gru<S_, A_>), dim3(gblocks), dim3(256), 0, h->stream, theta, obs, hidden, n, \
+                           h->P, logits, act, action);                                                            \
+        SES_HIP_TRY(hipGetLastError());                                                                           \
+        return SES_OK;                                                                                            \
+    }
+        SES_GRU_CASE(4, 2)
+        SES_GRU_CASE(8, 4)
+#undef SES_GRU_CASE
+        return set_error(SES_ERR_UNSUPPORTED, "ses_policy_forward: no GRU kernel instance for num_state=%d num_action=%d", S, A);
+    }
+    const int blocks = ceil_div((long long)n * 4, 64);
 #define SES_FWD_CASE(S_, A_)                                                                                      \
     if (S == S_ && A == A_) {                                                                                     \
         hipLaunchKernelGGL((k_policy_forward_mlp<S_, A_>), dim3(blocks), dim3(64), 0, h->stream, theta, obs, n, h->P, \

@@ -1,0 +1,101 @@
+"""GRU policy (nn.GRU(32,32) cell, networks/neural_network.py:13-27) on the HIP path: the wave-per-offspring
+kernels of ses_gru.h against the C oracle (bit-exact) and the reference's own outputs (fixtures G1, G5-gru)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+RETURN_TOL = 1e-4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("S,A,disc", [(4, 2, True), (8, 4, False)])
+def test_gru_forward_bit_exact_over_a_sequence(S, A, disc):
+    from ses import HipES
+    h = HipES(None, S, A, disc, True)
+    rng = np.random.RandomState(S + A)
+    n, T = 203, 12
+    theta = (rng.randn(n, h.P) * rng.choice([0.1, 0.5, 1.5], size=(n, 1))).astype(np.float32)
+    hid_o = np.zeros((n, 32), np.float32)
+    hid_d = dev(hid_o.copy())
+    d_theta = dev(theta)
+    for t in range(T):
+        obs = (rng.randn(n, S) * rng.choice([0.05, 1.0, 3.0], size=(n, 1))).astype(np.float32)
+        if t == 0:
+            obs[:7] = 0.0
+        action, logits, act = h.policy_forward(d_theta, dev(obs), hid_d)
+        o_action, o_logits, o_act, hid_o = co.policy_forward(S, A, disc, True, theta, obs, hid_o)
+        assert np.array_equal(bits(hid_d.cpu().numpy()), bits(hid_o)), f"hidden state differs at step {t}"
+        assert np.array_equal(bits(logits.cpu().numpy()), bits(o_logits)), f"logits differ at step {t}"
+        assert np.array_equal(bits(act.cpu().numpy()), bits(o_act))
+        if disc:
+            assert np.array_equal(action.cpu().numpy(), o_action)
+    h.close()
+
+
+@pytest.mark.parametrize("ci", [1, 2, 6])
+def test_gru_forward_golden_g1(golden_dir, ci):
+    """Teacher-forced single steps against the reference module's outputs (fixture G1)."""
+    from ses import HipES
+    g1 = np.load(os.path.join(golden_dir, "g1_forward.npz"))
+    S, A, disc, gru = (int(v) for v in g1[f"c{ci}_cfg"])
+    assert gru
+    h = HipES(None, S, A, bool(disc), True)
+    theta, obs = g1[f"c{ci}_theta"], g1[f"c{ci}_obs"]
+    nets, T, _ = obs.shape
+    d_theta = dev(theta)
+    h_prev = np.zeros((nets, 32), np.float32)
+    for t in range(T):
+        hid = dev(h_prev)
+        action, logits, act = h.policy_forward(d_theta, dev(obs[:, t]), hid)
+        np.testing.assert_allclose(logits.cpu().numpy(), g1[f"c{ci}_logits"][:, t], rtol=2e-6, atol=2e-5)
+        np.testing.assert_allclose(hid.cpu().numpy(), g1[f"c{ci}_h"][:, t], rtol=0, atol=1e-5)
+        if disc:
+            assert np.array_equal(action.cpu().numpy(), g1[f"c{ci}_act"][:, t, 0].astype(np.int32))
+        else:
+            np.testing.assert_allclose(act.cpu().numpy(), g1[f"c{ci}_act"][:, t], rtol=0, atol=1e-5)
+        h_prev = g1[f"c{ci}_h"][:, t].copy()
+    h.close()
+
+
+@pytest.mark.parametrize("pomdp", [True, False])
+def test_gru_rollout_bit_exact_and_golden(golden_dir, pomdp):
+    from ses import HipES
+    g = np.load(os.path.join(golden_dir, "g56_rollouts.npz"))
+    theta, init = g["g5gru_theta"], g["init_states"]
+    es = HipES("CartPole-v1", 4, 2, True, True, pomdp=pomdp, max_step=500, eval_ep_num=5)
+    o_fit, o_ret, o_steps = co.rollout_cartpole(theta, init, 5, 500, gru=True, obs_mask=0b1010 if pomdp else 0)
+    for mode in (0, 1):
+        fit, ep_ret, ep_steps = es.rollout(dev(theta), dev(init), mode=mode, want_episodes=True)
+        assert np.array_equal(ep_steps.cpu().numpy(), o_steps)
+        assert np.array_equal(bits(fit.cpu().numpy()), bits(o_fit))
+    if pomdp:   # fixture G5-gru: reference RolloutWorker + reference GRU module over the POMDP CartPole
+        assert np.abs(o_fit.astype(np.float64) - g["g5gru_returns"]).max() <= RETURN_TOL
+    es.close()
+
+
+def test_gru_rollout_random_population_and_shards():
+    from ses import HipES
+    rng = np.random.RandomState(3)
+    n = 150
+    theta = (rng.randn(n, 6562) * 0.4).astype(np.float32)
+    init = rng.uniform(-0.05, 0.05, (n, 5, 4)).astype(np.float32)
+    es = HipES("CartPole-v1", 4, 2, True, True, pomdp=True, max_step=300, eval_ep_num=5)
+    fit = es.rollout(dev(theta), dev(init)).cpu().numpy()
+    o_fit, _, _ = co.rollout_cartpole(theta, init, 5, 300, gru=True, obs_mask=0b1010)
+    assert np.array_equal(bits(fit), bits(o_fit))
+    parts = np.concatenate([es.rollout(dev(theta[:37]), dev(init[:37])).cpu().numpy(),
+                            es.rollout(dev(theta[37:]), dev(init[37:])).cpu().numpy()])
+    assert np.array_equal(bits(parts), bits(fit))
+    es.close()
