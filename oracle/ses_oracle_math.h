@@ -58,16 +58,16 @@ static inline float o_expf(float x)
 }
 
 /* tanh: piecewise cubic on [0, 10) from the generated table (oracle/ses_tanh_table.h, DATA shared with
- * the device build), odd extension, 1.0 beyond.  d = ax - i/32 is exact in fp32. */
+ * the device build), odd extension, 1.0 beyond.  u = fract(ax*32) is exact in fp32. */
 static inline float o_tanhf(float x)
 {
-    const float ax = o_minf(fabsf(x), SES_TANH_XMAX);
-    const int32_t i = (int32_t)(ax * SES_TANH_H_INV);          /* truncation; ax*32 is exact */
-    const float d = o_fma((float)i, -SES_TANH_H, ax);
+    const float t = o_minf(fabsf(x), SES_TANH_XMAX) * SES_TANH_H_INV;   /* exact scaling by 32 */
+    const int32_t i = (int32_t)t;                                       /* truncation */
+    const float u = t - floorf(t);                                      /* v_fract_f32: exact */
     const float *c = SES_TANH_TABLE[i];
-    float p = o_fma(c[3], d, c[2]);
-    p = o_fma(p, d, c[1]);
-    p = o_fma(p, d, c[0]);
+    float p = o_fma(c[3], u, c[2]);
+    p = o_fma(p, u, c[1]);
+    p = o_fma(p, u, c[0]);
     return copysignf(p, x);
 }
 

@@ -25,25 +25,44 @@ struct CartPoleState {
 
 SES_DEV float clamp_sym(float v, float lim) { return min_(max_(v, -lim), lim); }
 
+// The step is split so that a fused kernel can overlap the action-independent half (sin/cos of the pole
+// angle, denominator) with the policy's LDS table reads; the arithmetic and its order are unchanged.
+struct CartPolePre {
+    float sn, cs, q, gsn, den;
+};
+
+SES_DEV CartPolePre cartpole_pre(const CartPoleState &s)
+{
+    CartPolePre p;
+    sincos_(s.th, p.sn, p.cs);
+    p.q = CP_PML_OVER_MASS * (s.thd * s.thd);
+    p.gsn = CP_GRAVITY * p.sn;
+    p.den = fma_(CP_DEN_C1, p.cs * p.cs, CP_DEN_C0);
+    return p;
+}
+
 // advances s in place; returns true when the NEW state is terminal
-SES_DEV bool cartpole_step(CartPoleState &s, int action)
+SES_DEV bool cartpole_post(CartPoleState &s, const CartPolePre &p, int action)
 {
     const float fom = action == 1 ? CP_FORCE_OVER_MASS : -CP_FORCE_OVER_MASS;
-    float sn, cs;
-    sincos_(s.th, sn, cs);
     // temp = (F + pml*thd^2*sin)/M ; thetaacc = (g*sin - cos*temp) / (l*(4/3 - mp*cos^2/M)) ;
     // xacc = temp - pml*thetaacc*cos/M   -- constant divisions folded into multipliers, one true division
-    const float temp = fma_(CP_PML_OVER_MASS * (s.thd * s.thd), sn, fom);
-    const float num = fma_(-cs, temp, CP_GRAVITY * sn);
-    const float den = fma_(CP_DEN_C1, cs * cs, CP_DEN_C0);
-    const float thacc = num / den;
-    const float xacc = fma_(-CP_PML_OVER_MASS * thacc, cs, temp);
+    const float temp = fma_(p.q, p.sn, fom);
+    const float num = fma_(-p.cs, temp, p.gsn);
+    const float thacc = num / p.den;
+    const float xacc = fma_(-CP_PML_OVER_MASS * thacc, p.cs, temp);
     const float nx = clamp_sym(fma_(CP_TAU, s.xd, s.x), CP_CLAMP);
     const float nxd = clamp_sym(fma_(CP_TAU, xacc, s.xd), CP_CLAMP);
     const float nth = clamp_sym(fma_(CP_TAU, s.thd, s.th), CP_CLAMP);
     const float nthd = clamp_sym(fma_(CP_TAU, thacc, s.thd), CP_CLAMP);
     s.x = nx; s.xd = nxd; s.th = nth; s.thd = nthd;
     return (nx < -CP_X_LIMIT) | (nx > CP_X_LIMIT) | (nth < -CP_THETA_LIMIT) | (nth > CP_THETA_LIMIT);
+}
+
+SES_DEV bool cartpole_step(CartPoleState &s, int action)
+{
+    const CartPolePre p = cartpole_pre(s);
+    return cartpole_post(s, p, action);
 }
 
 }  // namespace ses

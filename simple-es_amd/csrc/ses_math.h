@@ -52,23 +52,39 @@ SES_DEV float exp_(float x)
     return u2f(f2u(e) + ((uint32_t)ki << 23));
 }
 
-// 16-byte table entry: c0 + d*(c1 + d*(c2 + d*c3)) on [i/32, (i+1)/32)
+// 16-byte table entry: c0 + u*(c1 + u*(c2 + u*c3)), u = fract(|x|*32), on [i/32, (i+1)/32)
 struct alignas(16) TanhEntry {
     float c0, c1, c2, c3;
 };
 
 // tanh from the piecewise-cubic table (tools/gen_tanh_table.py); `tab` lives in LDS inside kernels.
-// 11 plain VALU instructions + one ds_read_b128, no division, no transcendental unit.
+// 9 plain VALU instructions + one ds_read_b128, no division, no transcendental unit.
+// tanh split in three so that callers can batch the table reads of several independent evaluations
+// (issue every ds_read_b128 first, evaluate the cubics afterwards: the LDS latency is paid once, not per value).
+SES_DEV int32_t tanh_index(float x, float &u)
+{
+    const float t = min_(__builtin_fabsf(x), SES_TANH_XMAX) * SES_TANH_H_INV;  // exact scaling by 32
+#if defined(__HIPCC__)
+    u = __builtin_amdgcn_fractf(t);                                            // v_fract_f32, exact
+#else
+    u = t - __builtin_floorf(t);
+#endif
+    return (int32_t)t;
+}
+
+SES_DEV float tanh_eval(const TanhEntry &c, float u, float x)
+{
+    float p = fma_(c.c3, u, c.c2);
+    p = fma_(p, u, c.c1);
+    p = fma_(p, u, c.c0);
+    return __builtin_copysignf(p, x);
+}
+
 SES_DEV float tanh_(const TanhEntry *tab, float x)
 {
-    const float ax = min_(__builtin_fabsf(x), SES_TANH_XMAX);
-    const int32_t i = (int32_t)(ax * SES_TANH_H_INV);
-    const float d = fma_((float)i, -SES_TANH_H, ax);  // exact
-    const TanhEntry c = tab[i];
-    float p = fma_(c.c3, d, c.c2);
-    p = fma_(p, d, c.c1);
-    p = fma_(p, d, c.c0);
-    return __builtin_copysignf(p, x);
+    float u;
+    const int32_t i = tanh_index(x, u);
+    return tanh_eval(tab[i], u, x);
 }
 
 // logistic sigmoid = 0.5 + 0.5*tanh(x/2)

@@ -76,17 +76,38 @@ struct MlpSlice {
         }
     }
 
-    // obs[S] -> logits[A] (identical in all LPE lanes of the env); tab: tanh table in LDS
-    __device__ __forceinline__ void forward(const TanhEntry *tab, const float (&obs)[S], float (&logits)[A]) const
+    // The forward pass is split in two so that a fused kernel can put env work that does not depend on the
+    // action between the table reads and their use:
+    //   begin(): all pre-activations + table indices, then ALL ds_read_b128 back to back
+    //   finish(): cubics, fc2, lane reduction.
+    // (Left to itself hipcc keeps only two ds_read_b128 in flight and waits on them four times per step:
+    //  22 % of the wave's cycles were SQ_WAIT_ANY.)
+    struct Pending {
+        float pre[U], frac[U];
+        TanhEntry ent[U];
+    };
+
+    __device__ __forceinline__ void begin(const TanhEntry *tab, const float (&obs)[S], Pending &pd) const
     {
-        float a[U];
+        int32_t idx[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float acc = b1[u];
 #pragma unroll
             for (int k = 0; k < S; ++k) acc = fma_(w1[u][k], obs[k], acc);
-            a[u] = tanh_(tab, acc);
+            pd.pre[u] = acc;
+            idx[u] = tanh_index(acc, pd.frac[u]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) pd.ent[u] = tab[idx[u]];
+    }
+
+    __device__ __forceinline__ void finish(const Pending &pd, float (&logits)[A]) const
+    {
+        float a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = tanh_eval(pd.ent[u], pd.frac[u], pd.pre[u]);
 #pragma unroll
         for (int o = 0; o < A; ++o) {
             float p[G];
@@ -111,6 +132,14 @@ struct MlpSlice {
             }
             logits[o] = lanes_sum<LPE>(s) + b2[o];
         }
+    }
+
+    // obs[S] -> logits[A] (identical in all LPE lanes of the env); tab: tanh table in LDS
+    __device__ __forceinline__ void forward(const TanhEntry *tab, const float (&obs)[S], float (&logits)[A]) const
+    {
+        Pending pd;
+        begin(tab, obs, pd);
+        finish(pd, logits);
     }
 };
 

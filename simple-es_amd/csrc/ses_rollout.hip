@@ -56,10 +56,13 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_cartpole_mlp(const float *__r
         obs[2] = (obs_mask & 4u) ? 0.0f : st.th;
         obs[3] = (obs_mask & 8u) ? 0.0f : st.thd;
         float logits[2];
-        net.forward(tanh_tab, obs, logits);
+        typename MlpSlice<4, 2, LPE>::Pending pending;
+        net.begin(tanh_tab, obs, pending);                 // fc1 + tanh table reads in flight ...
+        const CartPolePre pre = cartpole_pre(st);          // ... next to the action-independent half of the physics
+        net.finish(pending, logits);
         const int action = argmax_first<2>(logits);
         CartPoleState ns = st;
-        const bool term = cartpole_step(ns, action);
+        const bool term = cartpole_post(ns, pre, action);
         const bool advance = FIXED_LENGTH ? true : alive;  // episodic: a finished env is frozen
         st.x = advance ? ns.x : st.x;
         st.xd = advance ? ns.xd : st.xd;
