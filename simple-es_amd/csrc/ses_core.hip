@@ -31,6 +31,22 @@ int ensure_episode_scratch(ses_handle *h, size_t episodes)
     return SES_OK;
 }
 
+int ensure_reduce_scratch(ses_handle *h, size_t bytes)
+{
+    if (bytes <= h->red_cap) return SES_OK;
+    // grow generously: the buffer is re-used by every generation and a free/alloc pair would stall the stream
+    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes * 2;
+    if (h->red_scratch) {
+        SES_HIP_TRY(hipStreamSynchronize(h->stream));
+        SES_HIP_TRY(hipFree(h->red_scratch));
+    }
+    h->red_scratch = nullptr;
+    h->red_cap = 0;
+    SES_HIP_TRY(hipMalloc(&h->red_scratch, want));
+    h->red_cap = want;
+    return SES_OK;
+}
+
 }  // namespace ses
 
 extern "C" {

@@ -16,8 +16,8 @@ struct ses_handle {
     double *ep_return;   // [rows * E]
     int32_t *ep_steps;   // [rows * E]
     size_t ep_cap;       // capacity in episodes
-    double *red_scratch; // es_update partial sums
-    size_t red_cap;
+    void *red_scratch;   // rank keys (u64[n]) followed by es_update partial sums
+    size_t red_cap;      // bytes
 };
 
 namespace ses {
@@ -40,5 +40,6 @@ int set_error(int code, const char *fmt, ...);
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 int ensure_episode_scratch(ses_handle *h, size_t episodes);
+int ensure_reduce_scratch(ses_handle *h, size_t bytes);
 
 }  // namespace ses

@@ -87,26 +87,90 @@ __global__ __launch_bounds__(256) void k_init_states_uniform(uint64_t seed, uint
 
 // ------------------------------------------------------------------------------------------------ K4
 // rank[i] = #{ j : f[j] > f[i]  or (f[j] == f[i] and j > i) }   -- O(n^2) counting, exact and
-// order-independent (no sort).  2-D grid: blockIdx.x picks 256 offspring i, blockIdx.y a slice of JT
-// competitors j staged through LDS; partial counts are combined with integer atomics (deterministic).
-// The first version ran one block per 256 i over ALL j: 16 workgroups on a 256-CU chip, 110 us at n = 4096.
-__global__ __launch_bounds__(256) void k_rank_count(const float *__restrict__ fit, int n, int jt,
+// order-independent (no sort).  Each offspring gets a 64-bit key (order-preserving image of the float in
+// the high word, its index in the low word), so the whole tie rule is ONE unsigned 64-bit compare.
+// 2-D grid: blockIdx.x picks 256 offspring i, blockIdx.y a slice of jt competitors j whose keys are
+// wave-uniform and therefore fetched with scalar loads (no LDS, no vector memory in the loop); partial
+// counts are combined with integer atomics (deterministic).
+// History: v1 ran one block per 256 i over ALL j -- 16 workgroups on a 256-CU chip, 110 us at n = 4096;
+// v2 staged float tiles in LDS -- LDS-issue bound, 674 us at n = 65 536.
+__global__ __launch_bounds__(256) void k_rank_keys(const float *__restrict__ fit, int n,
+                                                   unsigned long long *__restrict__ keys,
+                                                   int32_t *__restrict__ rank)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t u = f2u(fit[i] + 0.0f);                       // -0 -> +0 so that -0 == +0 stays a tie
+    const uint32_t ordered = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    keys[i] = ((unsigned long long)ordered << 32) | (unsigned long long)(uint32_t)i;
+    rank[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_rank_count(const unsigned long long *__restrict__ keys, int n, int jt,
                                                     int32_t *__restrict__ rank)
 {
-    extern __shared__ float tile[];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int j0 = blockIdx.y * jt;
     const int lim = n - j0 < jt ? n - j0 : jt;
-    for (int k = threadIdx.x; k < lim; k += 256) tile[k] = fit[j0 + k];
-    __syncthreads();
-    if (i >= n) return;
-    const float fi = fit[i];
+    const unsigned long long ki = keys[i < n ? i : n - 1];
+    const unsigned long long *__restrict__ kj = keys + j0;       // uniform base: scalar loads below
     int count = 0;
-    for (int k = 0; k < lim; ++k) {
-        const float fj = tile[k];
-        count += (fj > fi) | ((fj == fi) & (j0 + k > i));
+    int k = 0;
+    for (; k + 16 <= lim; k += 16) {
+        unsigned long long c[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[e] = kj[k + e];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) count += (c[e] > ki) ? 1 : 0;
     }
-    if (count) atomicAdd(&rank[i], count);
+    for (; k < lim; ++k) count += (kj[k] > ki) ? 1 : 0;
+    if (i < n && count) atomicAdd(&rank[i], count);
+}
+
+// Large populations (n > RANK_SORT_MIN): sort tiles of RANK_TILE keys in LDS (bitonic network), then every
+// offspring binary-searches each sorted tile for the number of larger keys.  O(n log^2 T + n (n/T) log T)
+// instead of O(n^2).  Keys are distinct (index in the low
+// word), padding keys are 0 and never count as larger.
+constexpr int RANK_TILE = 1024;
+constexpr int RANK_SORT_MIN = 8192;
+
+__global__ __launch_bounds__(RANK_TILE / 2) void k_rank_tile_sort(const unsigned long long *__restrict__ keys, int n,
+                                                                  unsigned long long *__restrict__ sorted)
+{
+    __shared__ unsigned long long t[RANK_TILE];
+    const int base = blockIdx.x * RANK_TILE;
+    for (int e = threadIdx.x; e < RANK_TILE; e += RANK_TILE / 2) t[e] = base + e < n ? keys[base + e] : 0ull;
+    __syncthreads();
+    for (int k = 2; k <= RANK_TILE; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            {
+                const int p = threadIdx.x;                                // one compare-exchange per thread
+                const int lo = ((p & ~(j - 1)) << 1) | (p & (j - 1));   // insert a 0 bit at position log2(j)
+                const int hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const unsigned long long a = t[lo], b = t[hi];
+                if ((a > b) == up) { t[lo] = b; t[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int e = threadIdx.x; e < RANK_TILE; e += RANK_TILE / 2) sorted[base + e] = t[e];   // ascending
+}
+
+__global__ __launch_bounds__(256) void k_rank_search(const unsigned long long *__restrict__ keys,
+                                                     const unsigned long long *__restrict__ sorted, int n,
+                                                     int32_t *__restrict__ rank)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long ki = keys[i];
+    const unsigned long long *__restrict__ s = sorted + (size_t)blockIdx.y * RANK_TILE;   // one sorted tile
+    int lo = 0, hi = RANK_TILE;                      // first position with s[pos] > ki
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (s[mid] > ki) hi = mid; else lo = mid + 1;
+    }
+    if (lo < RANK_TILE) atomicAdd(&rank[i], RANK_TILE - lo);
 }
 
 __global__ __launch_bounds__(256) void k_rank_weights(const int32_t *__restrict__ rank, int n,
@@ -137,19 +201,26 @@ __device__ __forceinline__ void adam_apply(float g, double adam_a, float &mu, fl
     mu = (float)((double)mu + step);
 }
 
-// grad[p] = sum_i w_i * eps(i, p) with eps regenerated from Philox.
-// One 256-thread workgroup per parameter quad; thread c accumulates rows c, c+256, ... in ascending
-// order, then a fixed LDS tree combines the 256 partials: bit-reproducible for a given n, on any rank.
-__global__ __launch_bounds__(256) void k_es_update_philox(const double *__restrict__ weights, int n, int skip_row0,
-                                                          uint64_t seed, uint64_t gen, int P, float update_factor,
-                                                          double adam_a, float *__restrict__ mu,
-                                                          float *__restrict__ m, float *__restrict__ v,
-                                                          float *__restrict__ grad_out)
+// grad[p] = sum_i w_i * eps(i, p) with eps regenerated from Philox, in two stages:
+//   stage 1: one 256-thread workgroup per (parameter quad, chunk of ES_CHUNK = 4096 offspring); thread c
+//            accumulates rows c, c+256, ... of its chunk in ascending order, a fixed LDS tree combines the
+//            256 partials -> partial[chunk][p]
+//   stage 2: one thread per parameter adds the chunk partials in ascending chunk order, scales, applies Adam.
+// The order depends only on n, never on the GPU count (every rank computes all n rows), so mu stays
+// bit-identical across ranks.  (v1 was a single stage with one workgroup per quad: 57 workgroups, 141 us at
+// n = 65 536.)
+constexpr int ES_CHUNK = 4096;
+
+__global__ __launch_bounds__(256) void k_es_grad_partial(const double *__restrict__ weights, int n, int skip_row0,
+                                                         uint64_t seed, uint64_t gen, int P4,
+                                                         float *__restrict__ partial)
 {
     __shared__ float red[4][256];
     const int q = blockIdx.x;
+    const int row0 = blockIdx.y * ES_CHUNK;
+    const int row1 = row0 + ES_CHUNK < n ? row0 + ES_CHUNK : n;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = row0 + threadIdx.x; i < row1; i += 256) {
         if (skip_row0 && i == 0) continue;
         const float w = (float)weights[i];
         float z[4];
@@ -167,16 +238,23 @@ __global__ __launch_bounds__(256) void k_es_update_philox(const double *__restri
         }
         __syncthreads();
     }
-    if (threadIdx.x < 4) {
-        const int p = 4 * q + threadIdx.x;
-        if (p < P) {
-            const float g = red[threadIdx.x][0] * update_factor;  // offspring_strategies.py:414
-            if (grad_out) grad_out[p] = g;
-            float muv = mu[p], mv = m[p], vv = v[p];
-            adam_apply(g, adam_a, muv, mv, vv);
-            mu[p] = muv; m[p] = mv; v[p] = vv;
-        }
-    }
+    if (threadIdx.x < 4) partial[(size_t)blockIdx.y * P4 + 4 * q + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(256) void k_es_apply(const float *__restrict__ partial, int chunks, int P, int P4,
+                                                  float update_factor, double adam_a, float *__restrict__ mu,
+                                                  float *__restrict__ m, float *__restrict__ v,
+                                                  float *__restrict__ grad_out)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    float sum = partial[p];
+    for (int c = 1; c < chunks; ++c) sum = sum + partial[(size_t)c * P4 + p];
+    const float g = sum * update_factor;  // offspring_strategies.py:414
+    if (grad_out) grad_out[p] = g;
+    float muv = mu[p], mv = m[p], vv = v[p];
+    adam_apply(g, adam_a, muv, mv, vv);
+    mu[p] = muv; m[p] = mv; v[p] = vv;
 }
 
 // Reference-order accumulation over stored (mu + eps) rows: one thread per parameter, sequential over
@@ -301,9 +379,20 @@ int ses_rank_center(ses_handle *h, const float *fitness, int32_t n, int32_t *ran
     long long jt = ((long long)n * n / (256ll * 2048ll) + 63) / 64 * 64;
     if (jt < 64) jt = 64;
     if (jt > 8192) jt = 8192;
-    SES_HIP_TRY(hipMemsetAsync(rank, 0, sizeof(int32_t) * (size_t)n, h->stream));
-    hipLaunchKernelGGL(k_rank_count, dim3(ceil_div(n, 256), ceil_div(n, jt)), dim3(256), sizeof(float) * jt, h->stream,
-                       fitness, n, (int)jt, rank);
+    const int tiles = ceil_div(n, RANK_TILE);
+    const size_t key_bytes = (sizeof(unsigned long long) * (size_t)n + 255) / 256 * 256;
+    const int rc = ensure_reduce_scratch(h, key_bytes + sizeof(unsigned long long) * (size_t)tiles * RANK_TILE);
+    if (rc != SES_OK) return rc;
+    unsigned long long *keys = (unsigned long long *)h->red_scratch;
+    hipLaunchKernelGGL(k_rank_keys, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, fitness, n, keys, rank);
+    if (n > RANK_SORT_MIN) {
+        unsigned long long *sorted = (unsigned long long *)((char *)h->red_scratch + key_bytes);
+        hipLaunchKernelGGL(k_rank_tile_sort, dim3(tiles), dim3(RANK_TILE / 2), 0, h->stream, keys, n, sorted);
+        hipLaunchKernelGGL(k_rank_search, dim3(ceil_div(n, 256), tiles), dim3(256), 0, h->stream, keys, sorted, n, rank);
+    } else {
+        hipLaunchKernelGGL(k_rank_count, dim3(ceil_div(n, 256), ceil_div(n, jt)), dim3(256), 0, h->stream, keys, n,
+                           (int)jt, rank);
+    }
     if (weights)
         hipLaunchKernelGGL(k_rank_weights, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, rank, n, weights);
     SES_HIP_TRY(hipGetLastError());
@@ -320,8 +409,16 @@ int ses_es_update_philox(ses_handle *h, const double *weights, int32_t n, int32_
     // offspring_strategies.py:406-408: python-float factor, applied to a float32 array (weak scalar -> f32)
     double uf = lr / ((double)n * sigma);
     uf *= -1.0;
-    const int quads = (h->P + 3) / 4;
-    hipLaunchKernelGGL(k_es_update_philox, dim3(quads), dim3(256), 0, h->stream, weights, n, skip_row0, seed, gen, h->P,
+    const int quads = (h->P + 3) / 4, P4 = 4 * quads;
+    const int chunks = ceil_div(n, ES_CHUNK);
+    // partial sums live behind the rank keys in the handle's scratch (keys: n * 8 bytes)
+    const size_t key_bytes = (sizeof(unsigned long long) * (size_t)n + 255) / 256 * 256;
+    const int rc = ensure_reduce_scratch(h, key_bytes + sizeof(float) * (size_t)chunks * P4);
+    if (rc != SES_OK) return rc;
+    float *partial = (float *)((char *)h->red_scratch + key_bytes);
+    hipLaunchKernelGGL(k_es_grad_partial, dim3(quads, chunks), dim3(256), 0, h->stream, weights, n, skip_row0, seed, gen,
+                       P4, partial);
+    hipLaunchKernelGGL(k_es_apply, dim3(ceil_div(h->P, 256)), dim3(256), 0, h->stream, partial, chunks, h->P, P4,
                        (float)uf, adam_a, mu, m, v, grad_out);
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;

@@ -259,7 +259,7 @@ def test_rollout_full_size_properties(es):
 
 
 # ----------------------------------------------------------------------------------------- K4-K6
-@pytest.mark.parametrize("n", [2, 16, 97, 1025, 4096])
+@pytest.mark.parametrize("n", [2, 16, 97, 1025, 4096, 8192, 8193, 20001, 65536])
 def test_rank_center(es, n):
     rng = np.random.RandomState(n)
     fit = rng.permutation(n).astype(np.float32) * 0.5 + 3            # tie-free
