@@ -42,6 +42,8 @@ extern "C" {
 /* env_id */
 #define SES_ENV_NONE (-1)  /* no env: handle only serves policy-forward / strategy kernels */
 #define SES_ENV_CARTPOLE 0 /* CartPole-v1 via envs/gym_wrapper.py:7-54 (conf/cartpole.yaml) */
+#define SES_ENV_SIMPLE_SPREAD 2 /* pettingzoo MPE simple_spread via envs/pettingzoo_wrapper.py:6-64 (conf/simplespread.yaml); */
+                                /* num_state = 6*n_agents, num_action = 5, discrete, MLP policy shared by the agents      */
 
 /* rollout / env-step mode */
 #define SES_MODE_EPISODIC 0     /* an env stops at done (reference semantics, loop.py:116)      */
@@ -61,6 +63,7 @@ typedef struct ses_config {
     int32_t eval_ep_num;     /* --eval-ep-num, run_es.py:33-38                                   */
     int32_t device;          /* HIP device ordinal                                               */
     int32_t lanes_per_env;   /* 0 = choose from the population size; else 1, 2, 4 or 8           */
+    int32_t n_agents;        /* simple_spread: agents (= landmarks) per env, 2 (reference) or 3; else 1 */
 } ses_config;
 
 /* ---- lifecycle --------------------------------------------------------------------------- */
@@ -102,11 +105,12 @@ int ses_noise(ses_handle *h, uint64_t seed, uint64_t gen, int64_t first_row, int
 int ses_perturb_host_noise(ses_handle *h, const float *parents, const int32_t *parent_idx,
                            const double *eps64, double sigma, int32_t n_rows, float *theta,
                            float *eps_store);
-/* CartPole reset distribution U(lo,hi)^S from the ENV_INIT Philox stream, out[n_rows,E,S];
- * shared != 0 keys every row as offspring 0 (common random numbers).  The reference never seeds
- * its env: initial states are an explicit input of this library. */
+/* Reset distribution U(lo,hi)^width from the ENV_INIT Philox stream, out[n_rows,E,width]
+ * (CartPole: width 4, U(-0.05,0.05); simple_spread: width 4*n_agents = agent then landmark positions,
+ * U(-1,1)).  shared != 0 keys every row as offspring 0 (common random numbers).  The reference never
+ * seeds its env: initial states are an explicit input of this library. */
 int ses_init_states_uniform(ses_handle *h, uint64_t seed, uint64_t gen, int64_t first_row, int32_t n_rows,
-                            int32_t shared, float lo, float hi, float *out);
+                            int32_t shared, int32_t width, float lo, float hi, float *out);
 
 /* ---- K2: population-batched policy forward (networks/neural_network.py:20-36) ------------- */
 /* n independent (row, observation[, hidden]) triples.  hidden: float32[n,32] in/out, NULL for MLP.
@@ -124,7 +128,8 @@ int ses_env_step(ses_handle *h, int32_t n, int32_t mode, float *x, float *xd, fl
 
 /* ---- fused rollout: RolloutWorker for the whole shard (loop.py:108-125) -------------------- */
 /*
- * theta[n_rows,P]; init: float32 [E,S] (init_per_offspring = 0, shared) or [n_rows,E,S].
+ * theta[n_rows,P]; init: float32 [E,W] (init_per_offspring = 0, shared) or [n_rows,E,W], W = 4 for
+ * CartPole (the state), 4*n_agents for simple_spread (agent positions, landmark positions).
  * fitness[n_rows] = sum over the E episodes of the undiscounted return / E  (loop.py:124).
  * ep_return (float64[n_rows,E]) and ep_steps (int32[n_rows,E]) may be NULL.
  * The whole episode loop (policy forward + env step, <= max_step iterations) runs inside one kernel

@@ -124,3 +124,32 @@ def rollout_cartpole(theta, init, E, max_step, *, S=4, A=2, discrete=True, gru=F
                              ctypes.c_uint32(obs_mask), _p(theta), _p(init), ctypes.c_int(per),
                              _p(ep_ret), _p(ep_steps), _p(fit))
     return fit, ep_ret, ep_steps
+
+
+def spread_obs(n_agents, state, agent):
+    state = _f32(state)
+    obs = np.empty(6 * n_agents, dtype=np.float32)
+    lib().o_spread_obs(ctypes.c_int(n_agents), _p(state), ctypes.c_int(agent), _p(obs))
+    return obs
+
+
+def spread_step(n_agents, state, action):
+    """state float32[6n] updated in place; returns the team reward of the cycle."""
+    action = np.ascontiguousarray(action, dtype=np.int32)
+    fn = lib().o_spread_step
+    fn.restype = ctypes.c_float
+    return float(fn(ctypes.c_int(n_agents), _p(state), _p(action)))
+
+
+def rollout_spread(theta, init, E, n_agents, max_cycles=25):
+    """Returns (fitness[N] f32, ep_return[N,E] f64)."""
+    theta = np.atleast_2d(_f32(theta))
+    N = theta.shape[0]
+    init = _f32(init)
+    per = 1 if init.ndim == 3 else 0
+    assert init.shape[-2:] == (E, 4 * n_agents), init.shape
+    ep_ret = np.empty((N, E), dtype=np.float64)
+    fit = np.empty(N, dtype=np.float32)
+    lib().o_rollout_spread(ctypes.c_int(n_agents), ctypes.c_int(N), ctypes.c_int(E), ctypes.c_int(max_cycles),
+                           _p(theta), _p(init), ctypes.c_int(per), _p(ep_ret), _p(fit))
+    return fit, ep_ret

@@ -394,3 +394,133 @@ void o_rollout_cartpole(int S, int A, int discrete, int gru, int N, int E, int m
         fitness[i] = (float)(total / (double)E);
     }
 }
+
+/* ========================================================================================== */
+/* MPE simple_spread (pettingzoo mpe, reached by the reference through
+ * envs/pettingzoo_wrapper.py:9,22-58).  pettingzoo is third-party and absent from the reference tree and
+ * from this image: PARITY UNPINNED at this boundary; the rules below follow SURVEY Appendix A.3 and are
+ * the build's own definition (fp32).
+ *   n agents (size 0.15, colliding, mass 1), n landmarks; dt 0.1, damping 0.25, contact force 1e2,
+ *   contact margin 1e-3, action sensitivity 5; 5 discrete actions {noop, -x, +x, -y, +y};
+ *   team reward per cycle = sum_i [0.5*global + 0.5*local_i], global = -sum_landmarks min_agents dist,
+ *   local_i = -(number of OTHER agents closer than 0.3).
+ * State layout of one env: apos[2n] avel[2n] lpos[2n].  Observation of agent i (pettingzoo order):
+ *   vel_i(2) pos_i(2) landmark_k - pos_i (2n) agent_j - pos_i for j != i (2(n-1)) comm zeros (2(n-1)). */
+#define SP_MAXN 4
+#define SP_DT 0.1f
+#define SP_DAMP_KEEP 0.75f
+#define SP_CONTACT_FORCE 100.0f
+#define SP_CONTACT_MARGIN 1.0e-3f
+#define SP_INV_MARGIN 1000.0f
+#define SP_DIST_MIN 0.3f
+#define SP_SENS 5.0f
+
+/* softplus-style penetration: logaddexp(0, y) * k with y = -(dist - dist_min)/k */
+static inline float sp_penetration(float dist)
+{
+    const float y = -(dist - SP_DIST_MIN) * SP_INV_MARGIN;
+    const float ay = fabsf(y);
+    const float l1p = o_logf(1.0f + o_expf(-ay));       /* log(1 + e^-|y|) */
+    return (o_maxf(y, 0.0f) + l1p) * SP_CONTACT_MARGIN;
+}
+
+static void spread_obs(int n, const float *st, int i, float *obs)
+{
+    const float *ap = st, *av = st + 2 * n, *lp = st + 4 * n;
+    int o = 0;
+    obs[o++] = av[2 * i]; obs[o++] = av[2 * i + 1];
+    obs[o++] = ap[2 * i]; obs[o++] = ap[2 * i + 1];
+    for (int k = 0; k < n; ++k) { obs[o++] = lp[2 * k] - ap[2 * i]; obs[o++] = lp[2 * k + 1] - ap[2 * i + 1]; }
+    for (int j = 0; j < n; ++j) if (j != i) { obs[o++] = ap[2 * j] - ap[2 * i]; obs[o++] = ap[2 * j + 1] - ap[2 * i + 1]; }
+    for (int j = 0; j < n - 1; ++j) { obs[o++] = 0.0f; obs[o++] = 0.0f; }
+}
+
+/* one world step with the agents' discrete actions; returns the team reward of this cycle */
+static float spread_step(int n, float *st, const int *action)
+{
+    float *ap = st, *av = st + 2 * n;
+    const float *lp = st + 4 * n;
+    float fx[SP_MAXN], fy[SP_MAXN];
+    for (int i = 0; i < n; ++i) {
+        const int a = action[i];
+        fx[i] = a == 1 ? -SP_SENS : (a == 2 ? SP_SENS : 0.0f);
+        fy[i] = a == 3 ? -SP_SENS : (a == 4 ? SP_SENS : 0.0f);
+    }
+    for (int a = 0; a < n; ++a)
+        for (int b = a + 1; b < n; ++b) {
+            const float dx = ap[2 * a] - ap[2 * b], dy = ap[2 * a + 1] - ap[2 * b + 1];
+            const float dist = sqrtf(o_fma(dx, dx, dy * dy));
+            const float pen = sp_penetration(dist);
+            const float scale = dist > 0.0f ? (SP_CONTACT_FORCE * pen) / dist : 0.0f;
+            const float gx = dx * scale, gy = dy * scale;
+            fx[a] = gx + fx[a]; fy[a] = gy + fy[a];
+            fx[b] = fx[b] - gx; fy[b] = fy[b] - gy;
+        }
+    for (int i = 0; i < n; ++i) {
+        const float vx = o_fma(fx[i], SP_DT, av[2 * i] * SP_DAMP_KEEP);
+        const float vy = o_fma(fy[i], SP_DT, av[2 * i + 1] * SP_DAMP_KEEP);
+        av[2 * i] = vx; av[2 * i + 1] = vy;
+        ap[2 * i] = o_fma(vx, SP_DT, ap[2 * i]);
+        ap[2 * i + 1] = o_fma(vy, SP_DT, ap[2 * i + 1]);
+    }
+    float global = 0.0f;
+    for (int k = 0; k < n; ++k) {
+        float best = 0.0f;
+        for (int i = 0; i < n; ++i) {
+            const float dx = ap[2 * i] - lp[2 * k], dy = ap[2 * i + 1] - lp[2 * k + 1];
+            const float d = sqrtf(o_fma(dx, dx, dy * dy));
+            best = i == 0 ? d : o_minf(best, d);
+        }
+        global = global - best;
+    }
+    float team = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        float local = 0.0f;
+        for (int j = 0; j < n; ++j) if (j != i) {
+            const float dx = ap[2 * i] - ap[2 * j], dy = ap[2 * i + 1] - ap[2 * j + 1];
+            const float d = sqrtf(o_fma(dx, dx, dy * dy));
+            if (d < SP_DIST_MIN) local = local - 1.0f;
+        }
+        team = team + o_fma(0.5f, global, 0.5f * local);
+    }
+    return team;
+}
+
+/* single-env helpers for the Python env object */
+void o_spread_obs(int n, const float *st, int i, float *obs) { spread_obs(n, st, i, obs); }
+float o_spread_step(int n, float *st, const int32_t *action) { return spread_step(n, st, (const int *)action); }
+
+/*
+ * Population rollout for simple_spread: every agent of a team runs the SAME offspring network
+ * (learning_strategies/evolution/utils.py:4-8) on its own observation; team return summed over cycles
+ * (pettingzoo_wrapper.py:45-52, loop.py:123).  init: [E, 4n] (agent positions then landmark positions;
+ * velocities start at 0) shared, or [N, E, 4n].  S = 6n, A = 5, MLP policy.
+ */
+void o_rollout_spread(int n_agents, int N, int E, int max_cycles, const float *theta, const float *init,
+                      int init_per_offspring, double *ep_return, float *fitness)
+{
+    const int n = n_agents, S = 6 * n, A = 5;
+    const int P = o_param_count(S, A, 0);
+    for (int i = 0; i < N; ++i) {
+        net_view v = view_params(theta + (size_t)i * P, S, A, 0);
+        double total = 0.0;
+        for (int e = 0; e < E; ++e) {
+            const float *s0 = init + ((size_t)(init_per_offspring ? i : 0) * E + e) * 4 * n;
+            float st[6 * SP_MAXN];
+            for (int k = 0; k < 2 * n; ++k) { st[k] = s0[k]; st[2 * n + k] = 0.0f; st[4 * n + k] = s0[2 * n + k]; }
+            double ret = 0.0;
+            for (int t = 0; t < max_cycles; ++t) {
+                int action[SP_MAXN];
+                for (int a = 0; a < n; ++a) {
+                    float obs[6 * SP_MAXN], logits[SES_MAX_A];
+                    spread_obs(n, st, a, obs);
+                    action[a] = policy_forward(&v, S, A, 1, 0, obs, 0, logits, 0);
+                }
+                ret += (double)spread_step(n, st, action);
+            }
+            ep_return[(size_t)i * E + e] = ret;
+            total += ret;
+        }
+        fitness[i] = (float)(total / (double)E);
+    }
+}

@@ -1,9 +1,10 @@
 """build_env / build_network / build_loop with the reference's signatures and YAML keys (builder.py:10-86).
 
 Optional keys (all default to reference behaviour): strategy.noise ("philox" | "numpy"),
-strategy.seed, env.seed, env.shared_init.
+strategy.seed, env.seed, env.shared_init, env.n_agents (simple_spread: 2 like the reference, or 3).
 """
 from envs.gym_wrapper import GymWrapper
+from envs.pettingzoo_wrapper import PettingzooWrapper
 from learning_strategies.evolution.loop import ESLoop
 from learning_strategies.evolution.offspring_strategies import openai_es, simple_evolution, simple_genetic
 from networks.neural_network import GymEnvModel
@@ -18,7 +19,7 @@ _STRATEGIES = {
 
 def build_env(config):
     if config["name"] in _PETTINGZOO:
-        raise NotImplementedError(f"{config['name']}: the multi-agent env kernels are not built yet")
+        return PettingzooWrapper(config["name"], config["max_step"], n_agents=config.get("n_agents", 2))
     return GymWrapper(config["name"], config["max_step"], config["pomdp"])
 
 

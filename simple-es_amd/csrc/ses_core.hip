@@ -73,7 +73,8 @@ int ses_device_count(void)
 int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
 {
     SES_REQUIRE(cfg && out, "ses_create: null argument");
-    SES_REQUIRE(cfg->env_id == SES_ENV_CARTPOLE || cfg->env_id == SES_ENV_NONE, "ses_create: unknown env_id %d", cfg->env_id);
+    SES_REQUIRE(cfg->env_id == SES_ENV_CARTPOLE || cfg->env_id == SES_ENV_NONE || cfg->env_id == SES_ENV_SIMPLE_SPREAD,
+                "ses_create: unknown env_id %d", cfg->env_id);
     SES_REQUIRE(cfg->num_state >= 1 && cfg->num_state <= 32, "ses_create: num_state %d out of range", cfg->num_state);
     SES_REQUIRE(cfg->num_action >= 1 && cfg->num_action <= 8, "ses_create: num_action %d out of range", cfg->num_action);
     SES_REQUIRE(cfg->eval_ep_num >= 1, "ses_create: eval_ep_num must be >= 1");
@@ -84,6 +85,11 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     if (cfg->env_id == SES_ENV_CARTPOLE)
         SES_REQUIRE(cfg->num_state == 4 && cfg->num_action == 2 && cfg->discrete_action,
                     "ses_create: CartPole needs num_state=4 num_action=2 discrete_action=1");
+    if (cfg->env_id == SES_ENV_SIMPLE_SPREAD)
+        SES_REQUIRE((cfg->n_agents == 2 || cfg->n_agents == 3) && cfg->num_state == 6 * cfg->n_agents &&
+                        cfg->num_action == 5 && cfg->discrete_action && !cfg->gru,
+                    "ses_create: simple_spread needs n_agents in {2,3}, num_state=6*n_agents, num_action=5, "
+                    "discrete_action=1, gru=0");
     int ndev = ses_device_count();
     if (ndev <= 0) return ses::set_error(SES_ERR_NO_DEVICE, "ses_create: no HIP device visible");
     SES_REQUIRE(cfg->device >= 0 && cfg->device < ndev, "ses_create: device %d not in [0,%d)", cfg->device, ndev);

@@ -9,6 +9,7 @@
 #include "ses_gru.h"
 #include "ses_internal.h"
 #include "ses_policy.h"
+#include "ses_spread.h"
 
 namespace ses {
 
@@ -137,6 +138,53 @@ __global__ __launch_bounds__(256) void k_rollout_cartpole_gru(const float *__res
             if (ep_steps) ep_steps[(size_t)row * E + ep] = steps;
         }
     }
+}
+
+// simple_spread: NA agents per env share the offspring's MLP (utils.py:4-8: one deepcopy per agent, same
+// weights); per cycle every agent is evaluated on its own observation, then the world steps once
+// (pettingzoo_wrapper.py:36-52).  8 lanes per env: with S = 6*NA inputs the lane's weight slice is
+// 4 x (S + 1 + 5) registers.  Episodes last max_cycles (25) steps, so this kernel is short and dominated by
+// the one-time weight load; nothing is early-exited (all agents finish together).
+template <int NA>
+__global__ __launch_bounds__(64) void k_rollout_spread_mlp(const float *__restrict__ theta,
+                                                           const float *__restrict__ init, int init_per_offspring,
+                                                           int n_rows, int E, int P, int max_cycles,
+                                                           double *__restrict__ ep_return)
+{
+    constexpr int LPE = 8, S = 6 * NA, A = 5;
+    __shared__ TanhEntry tanh_tab[SES_TANH_N];
+    stage_tanh_table(tanh_tab);
+    const long long gtid = (long long)blockIdx.x * 64 + threadIdx.x;
+    const int n_env = n_rows * E;
+    int env = (int)(gtid / LPE);
+    const int sub = (int)(threadIdx.x % LPE);
+    const bool valid = env < n_env;
+    env = valid ? env : n_env - 1;
+    const int row = env / E;
+    const int ep = env - row * E;
+    MlpSlice<S, A, LPE> net;
+    net.load(theta + (size_t)row * P, sub);
+    const float *s0 = init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * (4 * NA);
+    SpreadState<NA> st;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        st.ax[i] = s0[2 * i]; st.ay[i] = s0[2 * i + 1];
+        st.vx[i] = 0.0f; st.vy[i] = 0.0f;
+        st.lx[i] = s0[2 * NA + 2 * i]; st.ly[i] = s0[2 * NA + 2 * i + 1];
+    }
+    double ret = 0.0;
+    for (int t = 0; t < max_cycles; ++t) {
+        int action[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            float obs[S], logits[A];
+            spread_obs<NA>(st, a, obs);
+            net.forward(tanh_tab, obs, logits);
+            action[a] = argmax_first<A>(logits);
+        }
+        ret += (double)spread_step<NA>(st, action);
+    }
+    if (valid && sub == 0) ep_return[env] = ret;
 }
 
 __global__ void k_fitness_mean(const double *__restrict__ ep_return, int n_rows, int E, float *__restrict__ fitness)
@@ -337,7 +385,8 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
     SES_REQUIRE(n_rows >= 1, "ses_rollout: n_rows must be >= 1");
     SES_REQUIRE(mode == SES_MODE_EPISODIC || mode == SES_MODE_FIXED_LENGTH, "ses_rollout: bad mode %d", mode);
     SES_REQUIRE((long long)n_rows * h->cfg.eval_ep_num * 8 < (1ll << 31), "ses_rollout: shard too large");
-    SES_REQUIRE(h->cfg.env_id == SES_ENV_CARTPOLE, "ses_rollout: handle has no env");
+    SES_REQUIRE(h->cfg.env_id == SES_ENV_CARTPOLE || h->cfg.env_id == SES_ENV_SIMPLE_SPREAD,
+                "ses_rollout: handle has no env");
     SES_HIP_TRY(hipSetDevice(h->cfg.device));
     const size_t episodes = (size_t)n_rows * h->cfg.eval_ep_num;
     double *epr = ep_return;
@@ -346,7 +395,16 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
         if (rc != SES_OK) return rc;
         epr = h->ep_return;
     }
-    if (h->cfg.gru) {
+    if (h->cfg.env_id == SES_ENV_SIMPLE_SPREAD) {
+        SES_REQUIRE(ep_steps == nullptr, "ses_rollout: simple_spread episodes have a fixed length, no ep_steps");
+        const int blocks = ceil_div((long long)episodes * 8, 64);
+        if (h->cfg.n_agents == 2)
+            hipLaunchKernelGGL((k_rollout_spread_mlp<2>), dim3(blocks), dim3(64), 0, h->stream, theta, init,
+                               init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, epr);
+        else
+            hipLaunchKernelGGL((k_rollout_spread_mlp<3>), dim3(blocks), dim3(64), 0, h->stream, theta, init,
+                               init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, epr);
+    } else if (h->cfg.gru) {
         const int blocks = ceil_div(n_rows, 4);
         if (mode == SES_MODE_FIXED_LENGTH)
             hipLaunchKernelGGL((k_rollout_cartpole_gru<true>), dim3(blocks), dim3(256), 0, h->stream, theta, init,

@@ -356,13 +356,13 @@ int ses_perturb_host_noise(ses_handle *h, const float *parents, const int32_t *p
 }
 
 int ses_init_states_uniform(ses_handle *h, uint64_t seed, uint64_t gen, int64_t first_row, int32_t n_rows,
-                            int32_t shared, float lo, float hi, float *out)
+                            int32_t shared, int32_t width, float lo, float hi, float *out)
 {
     SES_REQUIRE(h && out, "ses_init_states_uniform: null argument");
     SES_REQUIRE(n_rows >= 1 && first_row >= 0, "ses_init_states_uniform: row range");
     SES_HIP_TRY(hipSetDevice(h->cfg.device));
-    const int S = h->cfg.num_state, E = h->cfg.eval_ep_num;
-    SES_REQUIRE(E * 8 < (1 << 30) && S <= 32, "ses_init_states_uniform: shape");
+    const int S = width, E = h->cfg.eval_ep_num;
+    SES_REQUIRE(E * 8 < (1 << 30) && S >= 1 && S <= 32, "ses_init_states_uniform: shape");
     const long long threads = (long long)n_rows * E * ((S + 3) / 4);
     hipLaunchKernelGGL(k_init_states_uniform, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, seed, gen,
                        (long long)first_row, n_rows, E, S, shared, lo, hi - lo, out);

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("SES_LIB_PATH") or os.path.join(os.path.dirname(_HERE)
 SES_OK = 0
 ENV_NONE = -1
 ENV_CARTPOLE = 0
+ENV_SIMPLE_SPREAD = 2
 MODE_EPISODIC = 0
 MODE_FIXED_LENGTH = 1
 HIDDEN = 32
@@ -29,6 +30,7 @@ class SesConfig(ctypes.Structure):
         ("eval_ep_num", ctypes.c_int32),
         ("device", ctypes.c_int32),
         ("lanes_per_env", ctypes.c_int32),
+        ("n_agents", ctypes.c_int32),
     ]
 
 
@@ -51,7 +53,7 @@ SIGNATURES = {
     "ses_perturb": [_vp, _vp, _vp, _vp, _f32, _u64, _u64, _i64, _i32, _vp],
     "ses_noise": [_vp, _u64, _u64, _i64, _i32, _vp],
     "ses_perturb_host_noise": [_vp, _vp, _vp, _vp, _f64, _i32, _vp, _vp],
-    "ses_init_states_uniform": [_vp, _u64, _u64, _i64, _i32, _i32, _f32, _f32, _vp],
+    "ses_init_states_uniform": [_vp, _u64, _u64, _i64, _i32, _i32, _i32, _f32, _f32, _vp],
     "ses_policy_forward": [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "ses_env_step": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ses_rollout": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],

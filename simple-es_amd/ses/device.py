@@ -10,9 +10,9 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ENV_CARTPOLE, ENV_NONE, HIDDEN, MODE_EPISODIC, SesConfig, SesError, check
+from ._lib import ENV_CARTPOLE, ENV_NONE, ENV_SIMPLE_SPREAD, HIDDEN, MODE_EPISODIC, SesConfig, SesError, check
 
-ENV_IDS = {"CartPole-v1": ENV_CARTPOLE, "CartPole-v0": ENV_CARTPOLE, None: ENV_NONE}
+ENV_IDS = {"CartPole-v1": ENV_CARTPOLE, "CartPole-v0": ENV_CARTPOLE, "simple_spread": ENV_SIMPLE_SPREAD, None: ENV_NONE}
 
 
 def param_count(num_state, num_action, gru):
@@ -28,7 +28,7 @@ class HipES:
     the reference's builder.build_env / build_network (builder.py:10-24)."""
 
     def __init__(self, env_name="CartPole-v1", num_state=4, num_action=2, discrete_action=True, gru=False,
-                 pomdp=False, max_step=500, eval_ep_num=5, device=None, lanes_per_env=0):
+                 pomdp=False, max_step=500, eval_ep_num=5, device=None, lanes_per_env=0, n_agents=1):
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise SesError("no HIP device visible to torch: the simple-es hot path needs an MI355X "
@@ -42,8 +42,14 @@ class HipES:
         self.max_step, self.E = int(max_step), int(eval_ep_num)
         self.P = param_count(self.S, self.A, self.gru)
         self.env_id = ENV_IDS[env_name]
+        self.n_agents = int(n_agents)
+        # width of one initial-state row and its reset distribution
+        if self.env_id == ENV_SIMPLE_SPREAD:
+            self.init_dim, self.init_range = 4 * self.n_agents, (-1.0, 1.0)
+        else:
+            self.init_dim, self.init_range = 4, (-0.05, 0.05)
         cfg = SesConfig(self.env_id, self.S, self.A, int(self.discrete), int(self.gru), int(self.pomdp),
-                        self.max_step, self.E, int(device), int(lanes_per_env))
+                        self.max_step, self.E, int(device), int(lanes_per_env), self.n_agents)
         self._lib = lib
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -138,10 +144,12 @@ class HipES:
                                                int(n_rows), _ptr(theta), _ptr(store)), "ses_perturb_host_noise")
         return (theta, store) if want_eps_store else theta
 
-    def init_states_uniform(self, seed, gen, first_row, n_rows, shared=False, lo=-0.05, hi=0.05):
-        out = self.empty(n_rows, self.E, self.S)
+    def init_states_uniform(self, seed, gen, first_row, n_rows, shared=False, lo=None, hi=None):
+        lo = self.init_range[0] if lo is None else lo
+        hi = self.init_range[1] if hi is None else hi
+        out = self.empty(n_rows, self.E, self.init_dim)
         check(self._lib.ses_init_states_uniform(self._h, int(seed), int(gen), int(first_row), int(n_rows),
-                                                int(bool(shared)), float(lo), float(hi), _ptr(out)),
+                                                int(bool(shared)), int(self.init_dim), float(lo), float(hi), _ptr(out)),
               "ses_init_states_uniform")
         return out
 
@@ -173,14 +181,14 @@ class HipES:
         n_rows = theta.shape[0]
         self._chk(theta, "theta", torch.float32, (n_rows, self.P))
         if init.dim() == 2:
-            self._chk(init, "init", torch.float32, (self.E, self.S))
+            self._chk(init, "init", torch.float32, (self.E, self.init_dim))
             per = 0
         else:
-            self._chk(init, "init", torch.float32, (n_rows, self.E, self.S))
+            self._chk(init, "init", torch.float32, (n_rows, self.E, self.init_dim))
             per = 1
         fitness = self.empty(n_rows) if fitness is None else self._chk(fitness, "fitness", torch.float32, (n_rows,))
         ep_ret = self.empty(n_rows, self.E, dtype=torch.float64) if want_episodes else None
-        ep_steps = self.empty(n_rows, self.E, dtype=torch.int32) if want_episodes else None
+        ep_steps = self.empty(n_rows, self.E, dtype=torch.int32) if (want_episodes and self.env_id == ENV_CARTPOLE) else None
         check(self._lib.ses_rollout(self._h, _ptr(theta), _ptr(init), per, int(n_rows), int(mode), _ptr(fitness),
                                     _ptr(ep_ret), _ptr(ep_steps)), "ses_rollout")
         return (fitness, ep_ret, ep_steps) if want_episodes else fitness

@@ -269,8 +269,41 @@ def g56_rollouts():
         json.dump(meta, f, indent=1)
 
 
+# --------------------------------------------------------------------------- G7 (multi-agent)
+def g7_spread():
+    """Reference RolloutWorker over the build's simple_spread env: every agent of a team gets its own deepcopy
+    of the same network (utils.py:4-8); team return = sum of the agents' rewards (pettingzoo_wrapper.py:45-52)."""
+    from learning_strategies.evolution.utils import wrap_agentid  # reference
+    from oracle.spread_env import SimpleSpreadF32Env
+    out, meta = {}, {}
+    E = 5
+    for n_agents in (2, 3):
+        S = 6 * n_agents
+        net = GymEnvModel(S, 5, True, False)
+        P = flat(net).size
+        rng = np.random.RandomState(100 + n_agents)
+        theta = (rng.standard_normal((48, P)) * rng.choice([0.2, 0.7, 2.0], size=(48, 1))).astype(np.float32)
+        init = rng.uniform(-1, 1, (E, 4 * n_agents)).astype(np.float32)
+        env = SimpleSpreadF32Env(init, n_agents=n_agents)
+        rets = []
+        for i in range(theta.shape[0]):
+            load_flat(net, theta[i])
+            env.rewind()
+            rets.append(RolloutWorker((env, wrap_agentid(env.get_agent_ids(), net), E)))
+        out[f"n{n_agents}_theta"] = theta
+        out[f"n{n_agents}_init"] = init
+        out[f"n{n_agents}_returns"] = np.array(rets, dtype=np.float64)
+        meta[f"n{n_agents}"] = {"N": 48, "E": E, "P": int(P), "max_cycles": 25, "mean_return": float(np.mean(rets))}
+        print("G7 spread", n_agents, meta[f"n{n_agents}"])
+    np.savez_compressed(os.path.join(HERE, "g7_spread.npz"), **out)
+    with open(os.path.join(HERE, "g7_spread.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g234", "g56"]
+    which = sys.argv[1:] or ["g1", "g234", "g56", "g7"]
+    if "g7" in which:
+        g7_spread()
     if "g1" in which:
         g1_forward()
     if "g234" in which:

@@ -1,0 +1,79 @@
+"""simple_spread on the HIP path: fused multi-agent rollout vs the C oracle (bit-exact) and the reference
+fixture G7 (1e-4), plus the openai_es config of the reference (conf/simplespread.yaml) end to end."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "simple-es_amd")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("n_agents", [2, 3])
+def test_spread_rollout_golden_and_oracle(golden_dir, n_agents):
+    from ses import HipES
+    g = np.load(os.path.join(golden_dir, "g7_spread.npz"))
+    theta, init = g[f"n{n_agents}_theta"], g[f"n{n_agents}_init"]
+    es = HipES("simple_spread", 6 * n_agents, 5, True, False, max_step=25, eval_ep_num=5, n_agents=n_agents)
+    fit, ep_ret, _ = es.rollout(dev(theta), dev(init), want_episodes=True)
+    o_fit, o_ep = co.rollout_spread(theta, init, 5, n_agents)
+    assert np.array_equal(ep_ret.cpu().numpy().view(np.uint64), o_ep.view(np.uint64)), "episode returns differ from the oracle"
+    assert np.array_equal(fit.cpu().numpy().view(np.uint32), o_fit.view(np.uint32))
+    assert np.abs(fit.cpu().numpy().astype(np.float64) - g[f"n{n_agents}_returns"]).max() <= 1e-4
+    es.close()
+
+
+@pytest.mark.parametrize("n_agents", [2, 3])
+def test_spread_rollout_population_and_device_init(n_agents):
+    from ses import HipES
+    rng = np.random.RandomState(n_agents)
+    n = 333
+    es = HipES("simple_spread", 6 * n_agents, 5, True, False, max_step=25, eval_ep_num=4, n_agents=n_agents)
+    theta = (rng.randn(n, es.P) * rng.choice([0.2, 1.0, 3.0], size=(n, 1))).astype(np.float32)
+    init = es.init_states_uniform(7, 3, 100, n)                          # [n, E, 4*n_agents], U(-1,1)
+    want_init = co.init_states_uniform(7, 3, 100, n, 4, 4 * n_agents, False, -1.0, 1.0)
+    assert np.array_equal(init.cpu().numpy().view(np.uint32), want_init.view(np.uint32))
+    fit = es.rollout(dev(theta), init).cpu().numpy()
+    o_fit, _ = co.rollout_spread(theta, want_init, 4, n_agents)
+    assert np.array_equal(fit.view(np.uint32), o_fit.view(np.uint32))
+    # truncation through max_step (pettingzoo_wrapper.py:55-57)
+    es10 = HipES("simple_spread", 6 * n_agents, 5, True, False, max_step=10, eval_ep_num=4, n_agents=n_agents)
+    fit10 = es10.rollout(dev(theta), init).cpu().numpy()
+    assert np.array_equal(fit10.view(np.uint32), co.rollout_spread(theta, want_init, 4, n_agents, 10)[0].view(np.uint32))
+    es.close()
+    es10.close()
+
+
+def test_simplespread_yaml_runs_and_improves(tmp_path, monkeypatch):
+    import builder
+    monkeypatch.chdir(tmp_path)
+    cfg = yaml.load(open(os.path.join(SRC, "conf", "simplespread.yaml")), Loader=yaml.FullLoader)
+    assert cfg["env"]["max_step"] == "None"                               # the reference's string quirk survives
+    cfg["env"]["shared_init"] = True                                      # common random numbers: comparable generations
+    cfg["strategy"]["offspring_num"] = 512
+    loop = builder.build_loop(cfg, 60, 1, 5, False, 1000)
+    assert loop.env.get_agent_ids() == ["agent_0", "agent_1"] and loop.env.horizon == 25
+    from learning_strategies.evolution.loop import RolloutWorker
+    from learning_strategies.evolution.utils import wrap_agentid
+    from networks.neural_network import GymEnvModel
+
+    def validate(net):                                                    # 64 fixed episodes
+        loop.env._episode = 10 ** 6
+        return RolloutWorker((loop.env, wrap_agentid(loop.env.get_agent_ids(), net), 64))
+
+    zero = GymEnvModel(12, 5, True, False)
+    zero.zero_init()
+    before = validate(zero)                                               # all-noop team
+    loop.run()
+    after = validate(loop.offspring_strategy.get_elite_model())
+    assert after > before + 5, (before, after)                            # team return (negative distances) improves
