@@ -7,6 +7,7 @@
 
 `process_num` is accepted for command-line compatibility; the device path has no worker processes.
 """
+import json
 import os
 import time
 from collections import deque
@@ -79,6 +80,13 @@ class ESLoop(BaseESLoop):
 
             consumed_time = time.time() - start_time
             self.history.append((best_reward, curr_sigma))
+            self.ep5_rewards.append(best_reward)
+            if rank0:                                   # wandb-free metrics: same quantities as loop.py:94-99
+                with open(self.save_dir + "/metrics.jsonl", "a") as f:
+                    f.write(json.dumps({"episode": ep_num, "best_reward": best_reward, "curr_sigma": curr_sigma,
+                                        "ep5_mean_reward": sum(self.ep5_rewards) / len(self.ep5_rewards),
+                                        "time": consumed_time, "rollout_t": rollout_consumed_time,
+                                        "eval_t": eval_consumed_time}) + "\n")
             if rank0:
                 print(f"episode: {ep_num}, Best reward: {best_reward:.2f}, sigma: {curr_sigma:.3f}, "
                       f"time: {consumed_time:.2f}, rollout_t: {rollout_consumed_time:.2f}, "
@@ -86,7 +94,6 @@ class ESLoop(BaseESLoop):
 
             if self.log and rank0:
                 import wandb
-                self.ep5_rewards.append(best_reward)
                 wandb.log({"ep5_mean_reward": sum(self.ep5_rewards) / len(self.ep5_rewards),
                            "curr_sigma": curr_sigma})
 

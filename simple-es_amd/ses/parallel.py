@@ -32,7 +32,14 @@ class Shard:
             slot = local.new_full((self.per_rank,), float("-inf"))
             slot[: self.n_local] = local
         out = local.new_empty(self.per_rank * self.world)
-        dist.all_gather_into_tensor(out, slot.contiguous(), group=self.group)
+        if local.is_cuda and dist.get_backend(self.group) == "gloo":
+            # test rigs only (several ranks sharing one GPU, where RCCL refuses duplicate devices): stage the
+            # 4*N bytes through the host.  Production is backend "nccl" (RCCL) on device buffers.
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, slot.contiguous().cpu(), group=self.group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, slot.contiguous(), group=self.group)
         return out[: self.n_global].contiguous()
 
     def barrier(self):
