@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--max-step", type=int, default=500)
     ap.add_argument("--lanes-per-env", type=int, default=0)
     ap.add_argument("--roofline-envs", type=int, default=1 << 24)
+    ap.add_argument("--gru", action="store_true", help="GRU policy on POMDP CartPole instead of the headline MLP workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -98,7 +99,7 @@ def main():
     n_local, E, T = args.offspring_per_gpu, args.eval_ep_num, args.max_step
     n_global = n_local * world
     first = rank * n_local
-    es = HipES("CartPole-v1", 4, 2, True, False, max_step=T, eval_ep_num=E, device=local_rank,
+    es = HipES("CartPole-v1", 4, 2, True, args.gru, pomdp=args.gru, max_step=T, eval_ep_num=E, device=local_rank,
                lanes_per_env=args.lanes_per_env)
     lr, sigma0, decay, seed = 0.05, 0.1, 0.999, 0
     mu, m, v = es.zeros(es.P), es.zeros(es.P), es.zeros(es.P)
@@ -145,7 +146,8 @@ def main():
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "CartPole-v1 openai_es MLP(4-32-2, P=226), fixed-length episodes, termination masked",
+        "config": {"workload": ("POMDP CartPole-v1 openai_es GRU(4-32-GRU32-2, P=6562)" if args.gru else
+                                "CartPole-v1 openai_es MLP(4-32-2, P=226)") + ", fixed-length episodes, termination masked",
                    "offspring_per_gpu": n_local, "offspring_total": n_global, "eval_ep_num": E, "max_step": T,
                    "env_steps_per_generation": steps_per_gen, "noise": "rocRAND philox4x32_10",
                    "parallelism": f"population sharded over {world} GPU(s), fitness all-gather"},
@@ -166,6 +168,12 @@ def main():
                                     "bound": "valu-issue/latency (state and weights in VGPRs, no HBM traffic in the loop)"}
         if not args.no_roofline:
             result["roofline"] = env_step_roofline(es, args.roofline_envs)
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_env_step.json")
+            if os.path.exists(pmc) and args.roofline_envs == (1 << 24):
+                # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+                # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/prof_pmc.sh); not collectable in-process
+                result["roofline"]["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch"]
+                result["roofline"]["traffic_source"] = "profiles/r01_pmc_env_step.json"
         if world == 1 and not args.no_cpu_baseline:
             from oracle import ref_port
             result["cpu_baseline"] = ref_port.time_baseline()
