@@ -42,6 +42,9 @@ extern "C" {
 /* env_id */
 #define SES_ENV_NONE (-1)  /* no env: handle only serves policy-forward / strategy kernels */
 #define SES_ENV_CARTPOLE 0 /* CartPole-v1 via envs/gym_wrapper.py:7-54 (conf/cartpole.yaml) */
+#define SES_ENV_LUNARLANDER 1 /* LunarLanderContinuous-v2 via envs/gym_wrapper.py (conf/lunarlander_openai.yaml): a REDUCED   */
+                              /* rigid-body lander ("lite", csrc/ses_lander.h); num_state 8, num_action 4, continuous;      */
+                              /* pomdp zeroes obs 2,3,5 (LunarLanderPOMDP, gym_wrapper.py:57-66); init rows: 16 uniforms   */
 #define SES_ENV_SIMPLE_SPREAD 2 /* pettingzoo MPE simple_spread via envs/pettingzoo_wrapper.py:6-64 (conf/simplespread.yaml); */
                                 /* num_state = 6*n_agents, num_action = 5, discrete, MLP policy shared by the agents      */
 

@@ -153,3 +153,39 @@ def rollout_spread(theta, init, E, n_agents, max_cycles=25):
     lib().o_rollout_spread(ctypes.c_int(n_agents), ctypes.c_int(N), ctypes.c_int(E), ctypes.c_int(max_cycles),
                            _p(theta), _p(init), ctypes.c_int(per), _p(ep_ret), _p(fit))
     return fit, ep_ret
+
+
+def rollout_lander(theta, init, E, max_step=300, *, gru=True, obs_mask=0b101100):
+    """LunarLander-lite population rollout.  Returns (fitness[N], ep_return[N,E] f64, ep_steps[N,E])."""
+    theta = np.atleast_2d(_f32(theta))
+    N = theta.shape[0]
+    init = _f32(init)
+    per = 1 if init.ndim == 3 else 0
+    assert init.shape[-2:] == (E, 16), init.shape
+    ep_ret = np.empty((N, E), dtype=np.float64)
+    ep_steps = np.empty((N, E), dtype=np.int32)
+    fit = np.empty(N, dtype=np.float32)
+    lib().o_rollout_lander(ctypes.c_int(int(gru)), ctypes.c_int(N), ctypes.c_int(E), ctypes.c_int(max_step),
+                           ctypes.c_uint32(obs_mask), _p(theta), _p(init), ctypes.c_int(per), _p(ep_ret), _p(ep_steps),
+                           _p(fit))
+    return fit, ep_ret, ep_steps
+
+
+class LanderSim:
+    """one LunarLander-lite env driven step by step (used by oracle/lander_env.py)"""
+
+    def __init__(self):
+        self._buf = ctypes.create_string_buffer(lib().o_lander_state_size())
+        lib().o_lander_step.restype = ctypes.c_float
+
+    def reset(self, u16):
+        u16 = _f32(u16)
+        obs = np.empty(8, dtype=np.float32)
+        lib().o_lander_reset(self._buf, _p(u16), _p(obs))
+        return obs
+
+    def step(self, a0, a1):
+        obs = np.empty(8, dtype=np.float32)
+        done = ctypes.c_int32(0)
+        r = lib().o_lander_step(self._buf, ctypes.c_float(a0), ctypes.c_float(a1), _p(obs), ctypes.byref(done))
+        return obs, float(r), bool(done.value)

@@ -73,7 +73,8 @@ int ses_device_count(void)
 int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
 {
     SES_REQUIRE(cfg && out, "ses_create: null argument");
-    SES_REQUIRE(cfg->env_id == SES_ENV_CARTPOLE || cfg->env_id == SES_ENV_NONE || cfg->env_id == SES_ENV_SIMPLE_SPREAD,
+    SES_REQUIRE(cfg->env_id == SES_ENV_CARTPOLE || cfg->env_id == SES_ENV_NONE || cfg->env_id == SES_ENV_SIMPLE_SPREAD ||
+                    cfg->env_id == SES_ENV_LUNARLANDER,
                 "ses_create: unknown env_id %d", cfg->env_id);
     SES_REQUIRE(cfg->num_state >= 1 && cfg->num_state <= 32, "ses_create: num_state %d out of range", cfg->num_state);
     SES_REQUIRE(cfg->num_action >= 1 && cfg->num_action <= 8, "ses_create: num_action %d out of range", cfg->num_action);
@@ -85,6 +86,9 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     if (cfg->env_id == SES_ENV_CARTPOLE)
         SES_REQUIRE(cfg->num_state == 4 && cfg->num_action == 2 && cfg->discrete_action,
                     "ses_create: CartPole needs num_state=4 num_action=2 discrete_action=1");
+    if (cfg->env_id == SES_ENV_LUNARLANDER)
+        SES_REQUIRE(cfg->num_state == 8 && cfg->num_action == 4 && !cfg->discrete_action,
+                    "ses_create: LunarLanderContinuous needs num_state=8 num_action=4 discrete_action=0");
     if (cfg->env_id == SES_ENV_SIMPLE_SPREAD)
         SES_REQUIRE((cfg->n_agents == 2 || cfg->n_agents == 3) && cfg->num_state == 6 * cfg->n_agents &&
                         cfg->num_action == 5 && cfg->discrete_action && !cfg->gru,
@@ -99,7 +103,9 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     h->cfg = *cfg;
     h->stream = (hipStream_t)stream;
     h->P = ses_param_count(cfg->num_state, cfg->num_action, cfg->gru);
-    h->obs_mask = (cfg->pomdp && cfg->env_id == SES_ENV_CARTPOLE) ? 0xAu : 0u;  // obs[1], obs[3]
+    h->obs_mask = 0u;
+    if (cfg->pomdp && cfg->env_id == SES_ENV_CARTPOLE) h->obs_mask = 0xAu;      // obs[1], obs[3]  (gym_wrapper.py:73-77)
+    if (cfg->pomdp && cfg->env_id == SES_ENV_LUNARLANDER) h->obs_mask = 0x2Cu;  // obs[2,3,5]      (gym_wrapper.py:61-66)
     *out = h;
     return SES_OK;
 }

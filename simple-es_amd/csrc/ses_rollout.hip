@@ -7,6 +7,7 @@
 
 #include "ses_cartpole.h"
 #include "ses_gru.h"
+#include "ses_lander.h"
 #include "ses_internal.h"
 #include "ses_policy.h"
 #include "ses_spread.h"
@@ -136,6 +137,89 @@ __global__ __launch_bounds__(256) void k_rollout_cartpole_gru(const float *__res
         if (valid && lane == 0) {
             if (ep_return) ep_return[(size_t)row * E + ep] = (double)steps;
             if (ep_steps) ep_steps[(size_t)row * E + ep] = steps;
+        }
+    }
+}
+
+// LunarLander-lite: continuous control (tanh head, the env uses outputs 0 and 1 -- SURVEY 3.4-12), float
+// rewards accumulated in float64 like the reference's python sum (loop.py:123).  GRU: one offspring per wave
+// (the env is wave-uniform, so contact iterations are skipped by scalar branches while the lander is in
+// flight); MLP: 8 lanes per env.
+template <bool GRU>
+__global__ __launch_bounds__(256) void k_rollout_lander(const float *__restrict__ theta,
+                                                        const float *__restrict__ init, int init_per_offspring,
+                                                        int n_rows, int E, int P, int max_step, uint32_t obs_mask,
+                                                        double *__restrict__ ep_return, int32_t *__restrict__ ep_steps)
+{
+    constexpr int S = 8, A = 4, LPE = 8;
+    __shared__ TanhEntry tanh_tab[SES_TANH_N];
+    __shared__ __attribute__((aligned(16))) float vecs[4][64];
+    stage_tanh_table(tanh_tab);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if constexpr (GRU) {
+        int row = blockIdx.x * 4 + wave;
+        const bool valid = row < n_rows;
+        row = valid ? row : n_rows - 1;
+        GruSlice<S, A> net;
+        net.load(theta + (size_t)row * P, lane);
+        float *vec = vecs[wave];
+        for (int ep = 0; ep < E; ++ep) {
+            LanderState st;
+            ll_reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 16);
+            float h = 0.0f;
+            wave_lds_sync();
+            if (lane < 32) vec[32 + lane] = 0.0f;
+            wave_lds_sync();
+            double ret = 0.0;
+            int steps = 0;
+            bool done = false;
+            while (steps < max_step) {
+                if (__builtin_amdgcn_readfirstlane((int)done)) break;
+                float obs[S], logits[A];
+                ll_obs(st, obs);
+#pragma unroll
+                for (int k = 0; k < S; ++k) obs[k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
+                net.forward(tanh_tab, obs, h, vec, lane, logits);
+                const float a0 = tanh_(tanh_tab, logits[0]), a1 = tanh_(tanh_tab, logits[1]);
+                ret += (double)ll_step(st, a0, a1, done);
+                steps += 1;
+            }
+            if (valid && lane == 0) {
+                ep_return[(size_t)row * E + ep] = ret;
+                if (ep_steps) ep_steps[(size_t)row * E + ep] = steps;
+            }
+        }
+    } else {
+        const long long gtid = (long long)blockIdx.x * 256 + threadIdx.x;
+        const int n_env = n_rows * E;
+        int env = (int)(gtid / LPE);
+        const int sub = (int)(threadIdx.x % LPE);
+        const bool valid = env < n_env;
+        env = valid ? env : n_env - 1;
+        const int row = env / E, ep = env - row * E;
+        MlpSlice<S, A, LPE> net;
+        net.load(theta + (size_t)row * P, sub);
+        LanderState st;
+        ll_reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 16);
+        double ret = 0.0;
+        int steps = 0;
+        bool done = false;
+        for (int t = 0; t < max_step; ++t) {
+            if (__ballot(!done) == 0ull) break;
+            float obs[S], logits[A];
+            ll_obs(st, obs);
+#pragma unroll
+            for (int k = 0; k < S; ++k) obs[k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
+            net.forward(tanh_tab, obs, logits);
+            const float a0 = tanh_(tanh_tab, logits[0]), a1 = tanh_(tanh_tab, logits[1]);
+            LanderState ns = st;
+            bool nd;
+            const float r = ll_step(ns, a0, a1, nd);
+            if (!done) { st = ns; ret += (double)r; steps += 1; done = nd; }   // a finished env is frozen
+        }
+        if (valid && sub == 0) {
+            ep_return[env] = ret;
+            if (ep_steps) ep_steps[env] = steps;
         }
     }
 }
@@ -385,7 +469,8 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
     SES_REQUIRE(n_rows >= 1, "ses_rollout: n_rows must be >= 1");
     SES_REQUIRE(mode == SES_MODE_EPISODIC || mode == SES_MODE_FIXED_LENGTH, "ses_rollout: bad mode %d", mode);
     SES_REQUIRE((long long)n_rows * h->cfg.eval_ep_num * 8 < (1ll << 31), "ses_rollout: shard too large");
-    SES_REQUIRE(h->cfg.env_id == SES_ENV_CARTPOLE || h->cfg.env_id == SES_ENV_SIMPLE_SPREAD,
+    SES_REQUIRE(h->cfg.env_id == SES_ENV_CARTPOLE || h->cfg.env_id == SES_ENV_SIMPLE_SPREAD ||
+                    h->cfg.env_id == SES_ENV_LUNARLANDER,
                 "ses_rollout: handle has no env");
     SES_HIP_TRY(hipSetDevice(h->cfg.device));
     const size_t episodes = (size_t)n_rows * h->cfg.eval_ep_num;
@@ -395,7 +480,17 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
         if (rc != SES_OK) return rc;
         epr = h->ep_return;
     }
-    if (h->cfg.env_id == SES_ENV_SIMPLE_SPREAD) {
+    if (h->cfg.env_id == SES_ENV_LUNARLANDER) {
+        SES_REQUIRE(mode == SES_MODE_EPISODIC, "ses_rollout: LunarLander has no fixed-length mode");
+        if (h->cfg.gru)
+            hipLaunchKernelGGL((k_rollout_lander<true>), dim3(ceil_div(n_rows, 4)), dim3(256), 0, h->stream, theta, init,
+                               init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, epr,
+                               ep_steps);
+        else
+            hipLaunchKernelGGL((k_rollout_lander<false>), dim3(ceil_div((long long)episodes * 8, 256)), dim3(256), 0,
+                               h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
+                               h->cfg.max_step, h->obs_mask, epr, ep_steps);
+    } else if (h->cfg.env_id == SES_ENV_SIMPLE_SPREAD) {
         SES_REQUIRE(ep_steps == nullptr, "ses_rollout: simple_spread episodes have a fixed length, no ep_steps");
         const int blocks = ceil_div((long long)episodes * 8, 64);
         if (h->cfg.n_agents == 2)

@@ -9,7 +9,9 @@ import numpy as np
 import torch
 
 SUPPORTED = {"CartPole-v1": dict(num_state=4, num_action=2, discrete=True, time_limit=500),
-             "CartPole-v0": dict(num_state=4, num_action=2, discrete=True, time_limit=200)}
+             "CartPole-v0": dict(num_state=4, num_action=2, discrete=True, time_limit=200),
+             # reduced rigid-body lander ("lite", csrc/ses_lander.h) -- gym's own TimeLimit is 1000 steps
+             "LunarLanderContinuous-v2": dict(num_state=8, num_action=4, discrete=False, time_limit=1000)}
 
 
 class GymWrapper:
@@ -38,6 +40,8 @@ class GymWrapper:
 
     # ---- single-env protocol (playback) ---------------------------------------------------------
     def _device(self):
+        if "CartPole" not in self.name:
+            raise NotImplementedError(f"step-wise {self.name} is not exposed; use ESLoop / RolloutWorker (fused device rollout)")
         if self._dev is None:
             from ses import HipES
             self._dev = HipES(self.name, 4, 2, True, False, pomdp=self.pomdp, max_step=self.horizon, eval_ep_num=1)

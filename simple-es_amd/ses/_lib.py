@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("SES_LIB_PATH") or os.path.join(os.path.dirname(_HERE)
 SES_OK = 0
 ENV_NONE = -1
 ENV_CARTPOLE = 0
+ENV_LUNARLANDER = 1
 ENV_SIMPLE_SPREAD = 2
 MODE_EPISODIC = 0
 MODE_FIXED_LENGTH = 1

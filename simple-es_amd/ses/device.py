@@ -10,9 +10,10 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ENV_CARTPOLE, ENV_NONE, ENV_SIMPLE_SPREAD, HIDDEN, MODE_EPISODIC, SesConfig, SesError, check
+from ._lib import ENV_CARTPOLE, ENV_LUNARLANDER, ENV_NONE, ENV_SIMPLE_SPREAD, HIDDEN, MODE_EPISODIC, SesConfig, SesError, check
 
-ENV_IDS = {"CartPole-v1": ENV_CARTPOLE, "CartPole-v0": ENV_CARTPOLE, "simple_spread": ENV_SIMPLE_SPREAD, None: ENV_NONE}
+ENV_IDS = {"CartPole-v1": ENV_CARTPOLE, "CartPole-v0": ENV_CARTPOLE, "simple_spread": ENV_SIMPLE_SPREAD,
+           "LunarLanderContinuous-v2": ENV_LUNARLANDER, None: ENV_NONE}
 
 
 def param_count(num_state, num_action, gru):
@@ -46,6 +47,8 @@ class HipES:
         # width of one initial-state row and its reset distribution
         if self.env_id == ENV_SIMPLE_SPREAD:
             self.init_dim, self.init_range = 4 * self.n_agents, (-1.0, 1.0)
+        elif self.env_id == ENV_LUNARLANDER:
+            self.init_dim, self.init_range = 16, (0.0, 1.0)      # force, terrain heights, noise key (csrc/ses_lander.h)
         else:
             self.init_dim, self.init_range = 4, (-0.05, 0.05)
         cfg = SesConfig(self.env_id, self.S, self.A, int(self.discrete), int(self.gru), int(self.pomdp),
@@ -188,7 +191,7 @@ class HipES:
             per = 1
         fitness = self.empty(n_rows) if fitness is None else self._chk(fitness, "fitness", torch.float32, (n_rows,))
         ep_ret = self.empty(n_rows, self.E, dtype=torch.float64) if want_episodes else None
-        ep_steps = self.empty(n_rows, self.E, dtype=torch.int32) if (want_episodes and self.env_id == ENV_CARTPOLE) else None
+        ep_steps = self.empty(n_rows, self.E, dtype=torch.int32) if (want_episodes and self.env_id != ENV_SIMPLE_SPREAD) else None
         check(self._lib.ses_rollout(self._h, _ptr(theta), _ptr(init), per, int(n_rows), int(mode), _ptr(fitness),
                                     _ptr(ep_ret), _ptr(ep_steps)), "ses_rollout")
         return (fitness, ep_ret, ep_steps) if want_episodes else fitness

@@ -300,8 +300,34 @@ def g7_spread():
         json.dump(meta, f, indent=1)
 
 
+# --------------------------------------------------------------------------- G8 (continuous control, GRU)
+def g8_lander():
+    """conf/lunarlander_openai.yaml shape: GymEnvModel(8, 4, discrete_action=False, gru=True), POMDP mask,
+    max_step 300, reference RolloutWorker over the build's LunarLander-lite env."""
+    from oracle.lander_env import LunarLanderLiteEnv
+    E = 3
+    rng = np.random.RandomState(8)
+    net = GymEnvModel(8, 4, False, True)
+    P = flat(net).size
+    theta = (rng.standard_normal((24, P)) * rng.choice([0.05, 0.2, 0.5], size=(24, 1))).astype(np.float32)
+    init = rng.rand(E, 16).astype(np.float32)
+    env = LunarLanderLiteEnv(init, max_step=300, pomdp=True)
+    rets = []
+    for i in range(theta.shape[0]):
+        load_flat(net, theta[i])
+        env.rewind()
+        rets.append(RolloutWorker((env, {"0": net}, E)))
+    np.savez_compressed(os.path.join(HERE, "g8_lander.npz"), theta=theta, init=init, returns=np.array(rets, dtype=np.float64))
+    with open(os.path.join(HERE, "g8_lander.json"), "w") as f:
+        json.dump({"N": 24, "E": E, "P": int(P), "max_step": 300, "mean_return": float(np.mean(rets)),
+                   "min": float(np.min(rets)), "max": float(np.max(rets))}, f, indent=1)
+    print("G8 lander", float(np.mean(rets)), float(np.min(rets)), float(np.max(rets)))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g234", "g56", "g7"]
+    which = sys.argv[1:] or ["g1", "g234", "g56", "g7", "g8"]
+    if "g8" in which:
+        g8_lander()
     if "g7" in which:
         g7_spread()
     if "g1" in which:
