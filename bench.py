@@ -88,13 +88,19 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SES_BENCH_BACKEND", "nccl")      # "gloo": test rigs where ranks share one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from ses import HipES, MODE_FIXED_LENGTH
+    from ses.parallel import Shard
 
     n_local, E, T = args.offspring_per_gpu, args.eval_ep_num, args.max_step
     n_global = n_local * world
@@ -106,14 +112,14 @@ def main():
     init = es.init_states_uniform(seed, 0, 0, 1, shared=True)[0].contiguous()      # [E,4], common random numbers
     theta = es.empty(n_local, es.P)
     fit_local = es.empty(n_local)
-    fit_all = es.empty(n_global) if world > 1 else fit_local
+    shard = Shard(n_global)                                   # rank r owns rows [r*n_local, (r+1)*n_local)
+    assert (shard.first, shard.n_local) == (first, n_local)
     state = {"sigma": sigma0, "t": 0}
 
     def generation(gen):
         es.perturb(mu, state["sigma"], seed, gen, first, n_local, out=theta)        # row 0 of a real run is mu itself
         es.rollout(theta, init, mode=MODE_FIXED_LENGTH, fitness=fit_local)
-        if world > 1:
-            dist.all_gather_into_tensor(fit_all, fit_local)
+        fit_all = shard.allgather_fitness(fit_local)          # RCCL all-gather of N*4 bytes (no-op at world 1)
         _, w = es.rank_center(fit_all)
         state["t"] += 1
         t = state["t"]

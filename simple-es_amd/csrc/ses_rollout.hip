@@ -22,19 +22,17 @@ namespace ses {
 // between workgroups, so no XCD-aware remap is needed.
 // All state (4 floats of physics, the lane's slice of the weights, step counter) stays in VGPRs for
 // the whole episode; HBM is touched once at the start (theta row, initial state) and once at the end.
-template <int LPE, bool FIXED_LENGTH, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_rollout_cartpole_mlp(const float *__restrict__ theta,
-                                                             const float *__restrict__ init, int init_per_offspring,
-                                                             int n_rows, int E, int P, int max_step,
-                                                             uint32_t obs_mask, double *__restrict__ ep_return,
-                                                             int32_t *__restrict__ ep_steps)
+// One wave's share of the rollout: envs [env0 + wave_local_index ...), LPE lanes per env.
+template <int LPE, bool FIXED_LENGTH>
+__device__ __forceinline__ void rollout_cartpole_mlp_body(const TanhEntry *tanh_tab, long long lane_index, int env0,
+                                                          const float *__restrict__ theta,
+                                                          const float *__restrict__ init, int init_per_offspring,
+                                                          int n_env, int E, int P, int max_step, uint32_t obs_mask,
+                                                          double *__restrict__ ep_return,
+                                                          int32_t *__restrict__ ep_steps)
 {
-    __shared__ TanhEntry tanh_tab[SES_TANH_N];
-    stage_tanh_table(tanh_tab);
-    const long long gtid = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    const int n_env = n_rows * E;
-    int env = (int)(gtid / LPE);
-    const int sub = (int)(threadIdx.x % LPE);
+    int env = env0 + (int)(lane_index / LPE);
+    const int sub = (int)(lane_index % LPE);
     const bool valid = env < n_env;
     env = valid ? env : n_env - 1;  // keep every lane active (DPP needs full waves); only valid lanes store
     const int row = env / E;
@@ -78,6 +76,49 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_cartpole_mlp(const float *__r
     if (valid && sub == 0) {
         if (ep_return) ep_return[env] = (double)steps;  // CartPole reward is 1 per step incl. the terminal one
         if (ep_steps) ep_steps[env] = steps;
+    }
+}
+
+template <int LPE, bool FIXED_LENGTH, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_rollout_cartpole_mlp(const float *__restrict__ theta,
+                                                             const float *__restrict__ init, int init_per_offspring,
+                                                             int n_rows, int E, int P, int max_step,
+                                                             uint32_t obs_mask, double *__restrict__ ep_return,
+                                                             int32_t *__restrict__ ep_steps)
+{
+    __shared__ TanhEntry tanh_tab[SES_TANH_N];
+    stage_tanh_table(tanh_tab);
+    rollout_cartpole_mlp_body<LPE, FIXED_LENGTH>(tanh_tab, (long long)blockIdx.x * BLOCK + threadIdx.x, 0, theta, init,
+                                                 init_per_offspring, n_rows * E, E, P, max_step, obs_mask, ep_return,
+                                                 ep_steps);
+}
+
+// Mixed split for mid-sized populations.  A lone wave issues one VALU instruction per 4 cycles, so a SIMD
+// holding a single wave runs at half its issue rate, and with 20 480 envs neither split fills the 1024 SIMDs
+// evenly (LPE 4: 1280 waves, a quarter of the SIMDs carry two; LPE 8: 2560 waves, half carry three).
+// Here the first `waves8` single-wave workgroups take 8 envs each at 8 lanes per env -- the dispatcher deals
+// them one per SIMD -- and the remaining envs follow at 4 lanes per env, so every SIMD ends up with one light
+// wave (151 instructions per step) and at most one heavy wave (218).  Results do not depend on the split:
+// every LPE variant evaluates the same canonical arithmetic.
+template <bool FIXED_LENGTH>
+__global__ __launch_bounds__(64) void k_rollout_cartpole_mlp_mix(const float *__restrict__ theta,
+                                                                 const float *__restrict__ init,
+                                                                 int init_per_offspring, int n_rows, int E, int P,
+                                                                 int max_step, uint32_t obs_mask, int waves8,
+                                                                 double *__restrict__ ep_return,
+                                                                 int32_t *__restrict__ ep_steps)
+{
+    __shared__ TanhEntry tanh_tab[SES_TANH_N];
+    stage_tanh_table(tanh_tab);
+    const int n_env = n_rows * E;
+    if ((int)blockIdx.x < waves8) {
+        rollout_cartpole_mlp_body<8, FIXED_LENGTH>(tanh_tab, (long long)blockIdx.x * 64 + threadIdx.x, 0, theta, init,
+                                                   init_per_offspring, n_env < waves8 * 8 ? n_env : waves8 * 8, E, P,
+                                                   max_step, obs_mask, ep_return, ep_steps);
+    } else {
+        rollout_cartpole_mlp_body<4, FIXED_LENGTH>(tanh_tab, (long long)(blockIdx.x - waves8) * 64 + threadIdx.x,
+                                                   waves8 * 8, theta, init, init_per_offspring, n_env, E, P, max_step,
+                                                   obs_mask, ep_return, ep_steps);
     }
 }
 
@@ -457,6 +498,39 @@ static void launch_rollout(const ses_handle *h, const float *theta, const float 
     else launch_rollout_b<LPE, 64>(h, theta, init, per, n_rows, mode, ep_return, ep_steps);
 }
 
+static void launch_cartpole_mlp(const ses_handle *h, const float *theta, const float *init, int per, int n_rows,
+                                int mode, double *epr, int32_t *ep_steps)
+{
+    static const int allow_mix = [] {  // development knob: SES_ROLLOUT_MIX=0 disables the mixed split
+        const char *e = getenv("SES_ROLLOUT_MIX");
+        return e ? atoi(e) : 1;
+    }();
+    const long long episodes = (long long)n_rows * h->cfg.eval_ep_num;
+    if (h->cfg.lanes_per_env == 0 && allow_mix && episodes > 8192 && episodes <= 49152) {
+        static const int waves8_knob = [] {
+            const char *e = getenv("SES_ROLLOUT_WAVES8");
+            return e ? atoi(e) : 1024;                                  // one light wave per SIMD (256 CUs x 4)
+        }();
+        const int waves8 = (long long)waves8_knob * 8 < episodes ? waves8_knob : (int)(episodes / 8);
+        const int waves4 = ceil_div(episodes - 8ll * waves8, 16);
+        if (mode == SES_MODE_FIXED_LENGTH)
+            hipLaunchKernelGGL((k_rollout_cartpole_mlp_mix<true>), dim3(waves8 + waves4), dim3(64), 0, h->stream, theta,
+                               init, per, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, waves8, epr,
+                               ep_steps);
+        else
+            hipLaunchKernelGGL((k_rollout_cartpole_mlp_mix<false>), dim3(waves8 + waves4), dim3(64), 0, h->stream, theta,
+                               init, per, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, waves8, epr,
+                               ep_steps);
+        return;
+    }
+    switch (pick_lanes_per_env(h, episodes)) {
+        case 1: launch_rollout<1>(h, theta, init, per, n_rows, mode, epr, ep_steps); break;
+        case 2: launch_rollout<2>(h, theta, init, per, n_rows, mode, epr, ep_steps); break;
+        case 4: launch_rollout<4>(h, theta, init, per, n_rows, mode, epr, ep_steps); break;
+        default: launch_rollout<8>(h, theta, init, per, n_rows, mode, epr, ep_steps); break;
+    }
+}
+
 }  // namespace ses
 
 extern "C" {
@@ -509,12 +583,8 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
             hipLaunchKernelGGL((k_rollout_cartpole_gru<false>), dim3(blocks), dim3(256), 0, h->stream, theta, init,
                                init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
                                epr, ep_steps);
-    } else
-    switch (pick_lanes_per_env(h, (long long)episodes)) {
-        case 1: launch_rollout<1>(h, theta, init, init_per_offspring, n_rows, mode, epr, ep_steps); break;
-        case 2: launch_rollout<2>(h, theta, init, init_per_offspring, n_rows, mode, epr, ep_steps); break;
-        case 4: launch_rollout<4>(h, theta, init, init_per_offspring, n_rows, mode, epr, ep_steps); break;
-        default: launch_rollout<8>(h, theta, init, init_per_offspring, n_rows, mode, epr, ep_steps); break;
+    } else {
+        launch_cartpole_mlp(h, theta, init, init_per_offspring, n_rows, mode, epr, ep_steps);
     }
     hipLaunchKernelGGL(k_fitness_mean, dim3(ceil_div(n_rows, 256)), dim3(256), 0, h->stream, epr, n_rows,
                        h->cfg.eval_ep_num, fitness);
