@@ -173,6 +173,7 @@ def main():
                                     "env_steps_per_s_one_gpu": n_local * E * T / (roll_ms * 1e-3),
                                     "bound": "valu-issue/latency (state and weights in VGPRs, no HBM traffic in the loop)"}
         if not args.no_roofline:
+          try:
             result["roofline"] = env_step_roofline(es, args.roofline_envs)
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_env_step.json")
             if os.path.exists(pmc) and args.roofline_envs == (1 << 24):
@@ -180,9 +181,14 @@ def main():
                 # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/prof_pmc.sh); not collectable in-process
                 result["roofline"]["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch"]
                 result["roofline"]["traffic_source"] = "profiles/r01_pmc_env_step.json"
+          except Exception as exc:                                   # the headline line must still be printed
+            result["roofline_error"] = repr(exc)
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import ref_port
-            result["cpu_baseline"] = ref_port.time_baseline()
+            try:
+                from oracle import ref_port
+                result["cpu_baseline"] = ref_port.time_baseline()
+            except Exception as exc:
+                result["cpu_baseline_error"] = repr(exc)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

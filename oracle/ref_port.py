@@ -107,6 +107,15 @@ def time_baseline(process_num=None, offspring_per_proc=6, episodes=5, max_step=5
     theta = (rng.standard_normal((n, 226)) * 0.1).astype(np.float32)
     init = np.random.RandomState(0).uniform(-0.05, 0.05, (episodes, 4)).astype(np.float32)
     _, steps, dt = run_generation(theta, init, episodes, max_step, process_num, fixed_length=True)
+    # the same worker in-process on ONE core (loop.py:76, process_num == 1), smaller sample
+    _, steps1, dt1 = run_generation(theta[:8], init, episodes, max_step, 1, fixed_length=True)
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
     return {"value": steps / dt, "unit": "env-steps/s", "cores": process_num, "kind": "port",
             "sample": f"{n} offspring x {episodes} episodes x {max_step} fixed-length steps = {steps} env-steps "
-                      f"in {dt:.2f}s, mp.Pool({process_num}), batch-1 torch forward + Python CartPole per step"}
+                      f"in {dt:.2f}s, mp.Pool({process_num}), batch-1 torch forward + Python CartPole per step",
+            "value_1_process": steps1 / dt1, "cpu_model": model}
