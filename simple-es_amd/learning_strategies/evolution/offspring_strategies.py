@@ -92,7 +92,9 @@ class _DeviceStrategy(BaseOffspringStrategy):
         idx = torch.from_numpy(np.ascontiguousarray(parent_idx_host[lo:hi], dtype=np.int32)).to(self.dev.device)
         self._last = {"parents": parents, "idx_host": np.asarray(parent_idx_host, dtype=np.int32), "sigma": sigma,
                       "gen": self.gen, "shard": shard}
-        if self.noise == "philox":
+        if shard.n_local == 0:                      # more ranks than offspring: this rank idles through the rollout
+            theta = self.dev.empty(0, self.P)
+        elif self.noise == "philox":
             theta = self.dev.perturb(parents, sigma, self.seed, self.gen, lo, shard.n_local, parent_idx=idx)
         else:
             eps = np.zeros((n, self.P))
