@@ -202,14 +202,14 @@ __device__ __forceinline__ void adam_apply(float g, double adam_a, float &mu, fl
 }
 
 // grad[p] = sum_i w_i * eps(i, p) with eps regenerated from Philox, in two stages:
-//   stage 1: one 256-thread workgroup per (parameter quad, chunk of ES_CHUNK = 4096 offspring); thread c
+//   stage 1: one 256-thread workgroup per (parameter quad, chunk of ES_CHUNK = 1024 offspring); thread c
 //            accumulates rows c, c+256, ... of its chunk in ascending order, a fixed LDS tree combines the
 //            256 partials -> partial[chunk][p]
 //   stage 2: one thread per parameter adds the chunk partials in ascending chunk order, scales, applies Adam.
 // The order depends only on n, never on the GPU count (every rank computes all n rows), so mu stays
 // bit-identical across ranks.  (v1 was a single stage with one workgroup per quad: 57 workgroups, 141 us at
 // n = 65 536.)
-constexpr int ES_CHUNK = 4096;
+constexpr int ES_CHUNK = 1024;
 
 __global__ __launch_bounds__(256) void k_es_grad_partial(const double *__restrict__ weights, int n, int skip_row0,
                                                          uint64_t seed, uint64_t gen, int P4,
