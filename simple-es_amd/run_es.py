@@ -20,6 +20,15 @@ def set_seed(seed):
     random.seed(seed)
 
 
+def change_value(tree, key, value):
+    """set every occurrence of `key` in a nested config dict (what sweep_main.py:16-30 does for wandb sweeps)"""
+    for k, v in tree.items():
+        if k == key:
+            tree[k] = value
+        elif isinstance(v, dict):
+            change_value(v, key, value)
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--cfg-path", type=str, default="conf/cartpole.yaml", help="config file to run.")
@@ -30,6 +39,10 @@ def main():
     parser.add_argument("--eval-ep-num", type=int, default=5, help="number of model evaluaion per iteration.")
     parser.add_argument("--log", action="store_true", help="wandb log")
     parser.add_argument("--save-model-period", type=int, default=10, help="save model for every n iteration.")
+    # hyper-parameter overrides, the flag set of the reference's sweep driver (sweep_main.py:65-69); unset = keep YAML
+    for flag, typ in (("--init-sigma", float), ("--sigma-decay", float), ("--learning-rate", float),
+                      ("--elite-num", int), ("--offspring-num", int)):
+        parser.add_argument(flag, type=typ, default=None, help="override the strategy value of the config file.")
     args = parser.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -42,6 +55,9 @@ def main():
     set_seed(args.seed)
     with open(args.cfg_path) as f:
         config = yaml.load(f, Loader=yaml.FullLoader)
+    for key in ("init_sigma", "sigma_decay", "learning_rate", "elite_num", "offspring_num"):
+        if getattr(args, key) is not None:
+            change_value(config, key, getattr(args, key))
     config.setdefault("strategy", {}).setdefault("seed", args.seed)
     config.setdefault("env", {}).setdefault("seed", args.seed)
 
