@@ -172,6 +172,16 @@ def main():
         result["rollout_kernel"] = {"ms": roll_ms, "perturb_ms": ev[0].elapsed_time(ev[1]),
                                     "env_steps_per_s_one_gpu": n_local * E * T / (roll_ms * 1e-3),
                                     "bound": "valu-issue/latency (state and weights in VGPRs, no HBM traffic in the loop)"}
+        sq = os.path.join(ROOT, "profiles", "r01_sq_rollout.json")
+        if os.path.exists(sq) and not args.gru and n_local == 4096 and E == 5 and T == 500 and args.lanes_per_env == 0:
+            # VALU issue roofline of the fused kernel: instruction count from the committed SQ counter profile of
+            # this same workload, duration measured live above
+            prof = json.load(open(sq))
+            rate = prof["per_dispatch"]["SQ_INSTS_VALU"] / (roll_ms * 1e-3)
+            result["rollout_kernel"].update({"valu_wave_instr_per_s": rate,
+                                             "valu_issue_peak_per_s": prof["peak_valu_wave_instr_per_s"],
+                                             "valu_issue_frac": rate / prof["peak_valu_wave_instr_per_s"],
+                                             "valu_source": "profiles/r01_sq_rollout.json"})
         if not args.no_roofline:
           try:
             result["roofline"] = env_step_roofline(es, args.roofline_envs)
