@@ -7,6 +7,7 @@
 
 #include "ses_cartpole.h"
 #include "ses_gru.h"
+#include "ses_gru_lockstep.h"
 #include "ses_lander.h"
 #include "ses_internal.h"
 #include "ses_policy.h"
@@ -178,6 +179,139 @@ __global__ __launch_bounds__(256) void k_rollout_cartpole_gru(const float *__res
         if (valid && lane == 0) {
             if (ep_return) ep_return[(size_t)row * E + ep] = (double)steps;
             if (ep_steps) ep_steps[(size_t)row * E + ep] = steps;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lockstep GRU rollout (ses_gru_lockstep.h): one offspring per wave, up to 8 episodes advance together,
+// lane l owns the env of episode (l & 7).  EnvT adapts an env to the kernel.
+struct CartPoleLs {
+    static constexpr int S = 4, A = 2, INIT_W = 4;
+    struct State {
+        CartPoleState st;
+    };
+    __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u)
+    {
+        s.st = CartPoleState{u[0], u[1], u[2], u[3]};
+    }
+    __device__ static __forceinline__ void observe(const State &s, float (&obs)[S])
+    {
+        obs[0] = s.st.x; obs[1] = s.st.xd; obs[2] = s.st.th; obs[3] = s.st.thd;
+    }
+    // advance with the policy output; returns the reward, sets done.  `freeze`: keep the old state (finished env)
+    __device__ static __forceinline__ float step(State &s, const float (&logits)[A], const TanhEntry *, bool freeze,
+                                                 bool &done)
+    {
+        const int action = argmax_first<A>(logits);
+        CartPoleState ns = s.st;
+        done = cartpole_step(ns, action);
+        s.st.x = freeze ? s.st.x : ns.x;
+        s.st.xd = freeze ? s.st.xd : ns.xd;
+        s.st.th = freeze ? s.st.th : ns.th;
+        s.st.thd = freeze ? s.st.thd : ns.thd;
+        return 1.0f;
+    }
+};
+
+struct LanderLs {
+    static constexpr int S = 8, A = 4, INIT_W = 16;
+    struct State {
+        LanderState st;
+    };
+    __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u) { ll_reset(s.st, u); }
+    __device__ static __forceinline__ void observe(const State &s, float (&obs)[S]) { ll_obs(s.st, obs); }
+    __device__ static __forceinline__ float step(State &s, const float (&logits)[A], const TanhEntry *tab, bool freeze,
+                                                 bool &done)
+    {
+        const float a0 = tanh_(tab, logits[0]), a1 = tanh_(tab, logits[1]);
+        LanderState ns = s.st;
+        const float r = ll_step(ns, a0, a1, done);
+        if (!freeze) s.st = ns;
+        return r;
+    }
+};
+
+template <typename EnvT, bool FIXED_LENGTH, int NP>
+__device__ __forceinline__ void gru_lockstep_batch(const TanhEntry *tanh_tab, GruLockstepLds<EnvT::S, EnvT::A> &lds,
+                                                   const GruLockstep<EnvT::S, EnvT::A> &net, int lane, int nb,
+                                                   const float *__restrict__ init_rows, int max_step, uint32_t obs_mask,
+                                                   double *__restrict__ ret_out, int32_t *__restrict__ steps_out,
+                                                   bool valid_row)
+{
+    constexpr int S = EnvT::S, A = EnvT::A;
+    const int slot = lane & 7;
+    const bool owner_valid = slot < nb;
+    typename EnvT::State st;
+    EnvT::reset(st, init_rows + (size_t)(owner_valid ? slot : 0) * EnvT::INIT_W);   // padding slots replay episode 0
+    float hreg[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) hreg[p] = 0.0f;                                  // GymEnvModel.reset()
+    wave_lds_sync();
+    if (lane < 32) {
+#pragma unroll
+        for (int e = 0; e < GL_EB; ++e) lds.h[e][lane] = 0.0f;
+    }
+    double ret = 0.0;
+    int steps = 0;
+    bool alive = true;
+    for (int t = 0; t < max_step; ++t) {
+        if constexpr (!FIXED_LENGTH) {
+            if (__ballot(alive & owner_valid) == 0ull) break;
+        }
+        float obs[S];
+        EnvT::observe(st, obs);
+        if (lane < GL_EB) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) lds.obs[lane][k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
+        }
+        wave_lds_sync();
+        net.template step<NP>(tanh_tab, lds, hreg, lane);
+        float logits[A];
+        net.logits_of(lds, slot, logits);
+        bool term;
+        const bool freeze = FIXED_LENGTH ? false : !alive;
+        const float r = EnvT::step(st, logits, tanh_tab, freeze, term);
+        const int nsteps = steps + 1;
+        const bool finished = term | (nsteps >= max_step);
+        ret = alive ? ret + (double)r : ret;
+        steps = alive ? nsteps : steps;
+        alive = alive & !finished;
+    }
+    if (valid_row && lane < GL_EB && owner_valid) {
+        if (ret_out) ret_out[slot] = ret;
+        if (steps_out) steps_out[slot] = steps;
+    }
+}
+
+template <typename EnvT, bool FIXED_LENGTH>
+__global__ __launch_bounds__(256) void k_rollout_gru_lockstep(const float *__restrict__ theta,
+                                                              const float *__restrict__ init, int init_per_offspring,
+                                                              int n_rows, int E, int P, int max_step, uint32_t obs_mask,
+                                                              double *__restrict__ ep_return,
+                                                              int32_t *__restrict__ ep_steps)
+{
+    __shared__ TanhEntry tanh_tab[SES_TANH_N];
+    __shared__ __attribute__((aligned(16))) GruLockstepLds<EnvT::S, EnvT::A> ldsv[4];
+    stage_tanh_table(tanh_tab);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int row = blockIdx.x * 4 + wave;
+    const bool valid = row < n_rows;
+    row = valid ? row : n_rows - 1;
+    GruLockstepLds<EnvT::S, EnvT::A> &lds = ldsv[wave];
+    GruLockstep<EnvT::S, EnvT::A> net;
+    net.load(theta + (size_t)row * P, lane, lds);
+    wave_lds_sync();
+    for (int e0 = 0; e0 < E; e0 += GL_EB) {
+        const int nb = E - e0 < GL_EB ? E - e0 : GL_EB;
+        const float *rows = init + ((size_t)(init_per_offspring ? row : 0) * E + e0) * EnvT::INIT_W;
+        double *ro = ep_return ? ep_return + (size_t)row * E + e0 : nullptr;
+        int32_t *so = ep_steps ? ep_steps + (size_t)row * E + e0 : nullptr;
+        switch ((nb + 1) / 2) {
+            case 1: gru_lockstep_batch<EnvT, FIXED_LENGTH, 1>(tanh_tab, lds, net, lane, nb, rows, max_step, obs_mask, ro, so, valid); break;
+            case 2: gru_lockstep_batch<EnvT, FIXED_LENGTH, 2>(tanh_tab, lds, net, lane, nb, rows, max_step, obs_mask, ro, so, valid); break;
+            case 3: gru_lockstep_batch<EnvT, FIXED_LENGTH, 3>(tanh_tab, lds, net, lane, nb, rows, max_step, obs_mask, ro, so, valid); break;
+            default: gru_lockstep_batch<EnvT, FIXED_LENGTH, 4>(tanh_tab, lds, net, lane, nb, rows, max_step, obs_mask, ro, so, valid); break;
         }
     }
 }
@@ -498,6 +632,15 @@ static void launch_rollout(const ses_handle *h, const float *theta, const float 
     else launch_rollout_b<LPE, 64>(h, theta, init, per, n_rows, mode, ep_return, ep_steps);
 }
 
+static bool gru_sequential()
+{
+    static const bool v = [] {  // development knob: SES_GRU_SEQUENTIAL=1 selects the episode-after-episode GRU kernels
+        const char *e = getenv("SES_GRU_SEQUENTIAL");
+        return e && atoi(e) != 0;
+    }();
+    return v;
+}
+
 static void launch_cartpole_mlp(const ses_handle *h, const float *theta, const float *init, int per, int n_rows,
                                 int mode, double *epr, int32_t *ep_steps)
 {
@@ -556,7 +699,11 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
     }
     if (h->cfg.env_id == SES_ENV_LUNARLANDER) {
         SES_REQUIRE(mode == SES_MODE_EPISODIC, "ses_rollout: LunarLander has no fixed-length mode");
-        if (h->cfg.gru)
+        if (h->cfg.gru && !gru_sequential())
+            hipLaunchKernelGGL((k_rollout_gru_lockstep<LanderLs, false>), dim3(ceil_div(n_rows, 4)), dim3(256), 0,
+                               h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
+                               h->cfg.max_step, h->obs_mask, epr, ep_steps);
+        else if (h->cfg.gru)
             hipLaunchKernelGGL((k_rollout_lander<true>), dim3(ceil_div(n_rows, 4)), dim3(256), 0, h->stream, theta, init,
                                init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, epr,
                                ep_steps);
@@ -573,6 +720,16 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
         else
             hipLaunchKernelGGL((k_rollout_spread_mlp<3>), dim3(blocks), dim3(64), 0, h->stream, theta, init,
                                init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, epr);
+    } else if (h->cfg.gru && !gru_sequential()) {
+        const int blocks = ceil_div(n_rows, 4);
+        if (mode == SES_MODE_FIXED_LENGTH)
+            hipLaunchKernelGGL((k_rollout_gru_lockstep<CartPoleLs, true>), dim3(blocks), dim3(256), 0, h->stream, theta,
+                               init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
+                               epr, ep_steps);
+        else
+            hipLaunchKernelGGL((k_rollout_gru_lockstep<CartPoleLs, false>), dim3(blocks), dim3(256), 0, h->stream, theta,
+                               init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
+                               epr, ep_steps);
     } else if (h->cfg.gru) {
         const int blocks = ceil_div(n_rows, 4);
         if (mode == SES_MODE_FIXED_LENGTH)
