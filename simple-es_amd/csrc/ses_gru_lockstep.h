@@ -80,7 +80,9 @@ struct GruLockstep {
     // One time step for the episodes [0, 2*NP) of the batch.  hreg[p] is this lane's hidden unit for the episode
     // it finishes in pair p (episode 2p + kh).  lds.obs must hold the (masked) observations; on return lds.y holds
     // tanh(h') and lds.h the new hidden state.
-    template <int NP>
+    // ODD: the last pair holds a single real episode; its partner's contraction is skipped (its partial sums are
+    // taken as 0, the upper half then finishes a dummy episode whose rows nobody reads).
+    template <int NP, bool ODD>
     __device__ __forceinline__ void step(const TanhEntry *tab, GruLockstepLds<S, A> &lds, float (&hreg)[NP], int lane) const
     {
         const int j = lane & 31, kh = lane >> 5;
@@ -101,6 +103,11 @@ struct GruLockstep {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int e = 2 * p + q;
+                if (ODD && p == NP - 1 && q == 1) {
+#pragma unroll
+                    for (int g = 0; g < 6; ++g) part[q][g] = 0.0f;
+                    continue;
+                }
                 // all 8 slice reads of this episode are issued before the first fma needs one of them
                 const float4 *va = reinterpret_cast<const float4 *>(&lds.a[e][16 * kh]);
                 const float4 *vh = reinterpret_cast<const float4 *>(&lds.h[e][16 * kh]);

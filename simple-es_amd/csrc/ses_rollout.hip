@@ -232,7 +232,7 @@ struct LanderLs {
     }
 };
 
-template <typename EnvT, bool FIXED_LENGTH, int NP>
+template <typename EnvT, bool FIXED_LENGTH, int NP, bool ODD>
 __device__ __forceinline__ void gru_lockstep_batch(const TanhEntry *tanh_tab, GruLockstepLds<EnvT::S, EnvT::A> &lds,
                                                    const GruLockstep<EnvT::S, EnvT::A> &net, int lane, int nb,
                                                    const float *__restrict__ init_rows, int max_step, uint32_t obs_mask,
@@ -266,7 +266,7 @@ __device__ __forceinline__ void gru_lockstep_batch(const TanhEntry *tanh_tab, Gr
             for (int k = 0; k < S; ++k) lds.obs[lane][k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
         }
         wave_lds_sync();
-        net.template step<NP>(tanh_tab, lds, hreg, lane);
+        net.template step<NP, ODD>(tanh_tab, lds, hreg, lane);
         float logits[A];
         net.logits_of(lds, slot, logits);
         bool term;
@@ -307,12 +307,19 @@ __global__ __launch_bounds__(256) void k_rollout_gru_lockstep(const float *__res
         const float *rows = init + ((size_t)(init_per_offspring ? row : 0) * E + e0) * EnvT::INIT_W;
         double *ro = ep_return ? ep_return + (size_t)row * E + e0 : nullptr;
         int32_t *so = ep_steps ? ep_steps + (size_t)row * E + e0 : nullptr;
-        switch ((nb + 1) / 2) {
-            case 1: gru_lockstep_batch<EnvT, FIXED_LENGTH, 1>(tanh_tab, lds, net, lane, nb, rows, max_step, obs_mask, ro, so, valid); break;
-            case 2: gru_lockstep_batch<EnvT, FIXED_LENGTH, 2>(tanh_tab, lds, net, lane, nb, rows, max_step, obs_mask, ro, so, valid); break;
-            case 3: gru_lockstep_batch<EnvT, FIXED_LENGTH, 3>(tanh_tab, lds, net, lane, nb, rows, max_step, obs_mask, ro, so, valid); break;
-            default: gru_lockstep_batch<EnvT, FIXED_LENGTH, 4>(tanh_tab, lds, net, lane, nb, rows, max_step, obs_mask, ro, so, valid); break;
+#define SES_LS_CASE(NP_, ODD_)                                                                                        \
+    gru_lockstep_batch<EnvT, FIXED_LENGTH, NP_, ODD_>(tanh_tab, lds, net, lane, nb, rows, max_step, obs_mask, ro, so, valid)
+        switch (nb) {
+            case 1: SES_LS_CASE(1, true); break;
+            case 2: SES_LS_CASE(1, false); break;
+            case 3: SES_LS_CASE(2, true); break;
+            case 4: SES_LS_CASE(2, false); break;
+            case 5: SES_LS_CASE(3, true); break;
+            case 6: SES_LS_CASE(3, false); break;
+            case 7: SES_LS_CASE(4, true); break;
+            default: SES_LS_CASE(4, false); break;
         }
+#undef SES_LS_CASE
     }
 }
 

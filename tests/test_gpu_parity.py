@@ -375,3 +375,35 @@ def test_bad_arguments_raise_before_launch(es):
         es.rank_center(torch.zeros(1, device="cuda"))
     with pytest.raises(SesError):
         es.gather_rows(torch.zeros(4, 226, device="cuda"), torch.tensor([0, 4], dtype=torch.int32, device="cuda"))
+
+
+def test_raw_c_abi_error_paths(es):
+    """Straight through ctypes, no Python-side validation: bad arguments must come back as negative status codes
+    with a message -- never a launch."""
+    import ctypes
+    from ses import _lib
+    lib = _lib.load()
+    h = es._h
+    assert lib.ses_rollout(h, None, None, 0, 4, 0, None, None, None) == -1
+    assert b"null argument" in lib.ses_last_error()
+    t = torch.zeros(8, 226, device="cuda")
+    i = torch.zeros(5, 4, device="cuda")
+    f = torch.zeros(8, device="cuda")
+    p = lambda x: ctypes.c_void_p(x.data_ptr())
+    assert lib.ses_rollout(h, p(t), p(i), 0, 0, 0, p(f), None, None) == -1            # n_rows = 0
+    assert lib.ses_rollout(h, p(t), p(i), 0, 8, 7, p(f), None, None) == -1            # unknown mode
+    assert b"bad mode" in lib.ses_last_error()
+    r = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert lib.ses_rank_center(h, p(f), 1, p(r), None) == -1                          # n - 1 = 0 divides in the reference
+    assert lib.ses_elite_ids(h, p(r), 1, 2, p(r)) == -1                               # k > n
+    bad = _lib.SesConfig(0, 5, 2, 1, 0, 0, 500, 5, 0, 0, 1)                           # CartPole with num_state 5
+    out = ctypes.c_void_p()
+    assert lib.ses_create(ctypes.byref(bad), None, ctypes.byref(out)) == -1 and not out.value
+    bad = _lib.SesConfig(0, 4, 2, 1, 0, 0, 500, 5, 99, 0, 1)                          # device out of range
+    assert lib.ses_create(ctypes.byref(bad), None, ctypes.byref(out)) == -1
+    bad = _lib.SesConfig(7, 4, 2, 1, 0, 0, 500, 5, 0, 0, 1)                           # unknown env
+    assert lib.ses_create(ctypes.byref(bad), None, ctypes.byref(out)) == -1
+    assert lib.ses_destroy(None) == 0
+    # the handle is still healthy afterwards
+    fit = es.rollout(torch.zeros(8, 226, device="cuda"), torch.zeros(5, 4, device="cuda"))
+    assert fit.shape == (8,)
