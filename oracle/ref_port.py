@@ -109,6 +109,11 @@ def time_baseline(process_num=None, offspring_per_proc=6, episodes=5, max_step=5
     _, steps, dt = run_generation(theta, init, episodes, max_step, process_num, fixed_length=True)
     # the same worker in-process on ONE core (loop.py:76, process_num == 1), smaller sample
     _, steps1, dt1 = run_generation(theta[:8], init, episodes, max_step, 1, fixed_length=True)
+    # for scale: the compiled C oracle (same arithmetic as the kernels) on one core
+    from . import c_oracle
+    t0 = time.perf_counter()
+    c_oracle.rollout_cartpole(theta[:64], init, episodes, max_step, mode=c_oracle.MODE_FIXED_LENGTH)
+    c_rate = 64 * episodes * max_step / (time.perf_counter() - t0)
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -118,4 +123,4 @@ def time_baseline(process_num=None, offspring_per_proc=6, episodes=5, max_step=5
     return {"value": steps / dt, "unit": "env-steps/s", "cores": process_num, "kind": "port",
             "sample": f"{n} offspring x {episodes} episodes x {max_step} fixed-length steps = {steps} env-steps "
                       f"in {dt:.2f}s, mp.Pool({process_num}), batch-1 torch forward + Python CartPole per step",
-            "value_1_process": steps1 / dt1, "cpu_model": model}
+            "value_1_process": steps1 / dt1, "c_oracle_1_core": c_rate, "cpu_model": model}
