@@ -67,6 +67,8 @@ typedef struct ses_config {
     int32_t device;          /* HIP device ordinal                                               */
     int32_t lanes_per_env;   /* 0 = choose from the population size; else 1, 2, 4 or 8           */
     int32_t n_agents;        /* simple_spread: agents (= landmarks) per env, 2 (reference) or 3; else 1 */
+    int32_t physics64;       /* CartPole rollouts only: 1 = gym-order float64 dynamics (csrc/ses_cartpole.h),   */
+                             /* 0 = folded-constant fp32 (default, benchmark path)                              */
 } ses_config;
 
 /* ---- lifecycle --------------------------------------------------------------------------- */

@@ -107,8 +107,9 @@ def cartpole_step_soa(mode, max_step, x, xd, th, thd, action, ret, status):
 
 
 def rollout_cartpole(theta, init, E, max_step, *, S=4, A=2, discrete=True, gru=False,
-                     mode=MODE_EPISODIC, obs_mask=0):
-    """Returns (fitness[N] f32, ep_return[N,E] f64, ep_steps[N,E] i32)."""
+                     mode=MODE_EPISODIC, obs_mask=0, physics64=False):
+    """Returns (fitness[N] f32, ep_return[N,E] f64, ep_steps[N,E] i32).
+    physics64: gym-order float64 dynamics instead of the folded-constant fp32 ones."""
     theta = np.atleast_2d(_f32(theta))
     N = theta.shape[0]
     init = _f32(init)
@@ -119,7 +120,8 @@ def rollout_cartpole(theta, init, E, max_step, *, S=4, A=2, discrete=True, gru=F
     ep_ret = np.empty((N, E), dtype=np.float64)
     ep_steps = np.empty((N, E), dtype=np.int32)
     fit = np.empty(N, dtype=np.float32)
-    lib().o_rollout_cartpole(ctypes.c_int(S), ctypes.c_int(A), ctypes.c_int(int(discrete)), ctypes.c_int(int(gru)),
+    fn = lib().o_rollout_cartpole64 if physics64 else lib().o_rollout_cartpole
+    fn(ctypes.c_int(S), ctypes.c_int(A), ctypes.c_int(int(discrete)), ctypes.c_int(int(gru)),
                              ctypes.c_int(N), ctypes.c_int(E), ctypes.c_int(max_step), ctypes.c_int(mode),
                              ctypes.c_uint32(obs_mask), _p(theta), _p(init), ctypes.c_int(per),
                              _p(ep_ret), _p(ep_steps), _p(fit))

@@ -325,6 +325,32 @@ static int cartpole_step(float st[4], int action)
     return (st[0] < -CP_X_LIMIT) | (st[0] > CP_X_LIMIT) | (st[2] < -CP_THETA_LIMIT) | (st[2] > CP_THETA_LIMIT);
 }
 
+/* Gym-order float64 CartPole ("physics64"): the statements of gym's cartpole.py step() one by one, every
+ * operation a separately rounded IEEE double operation (no fma), with the deterministic o_sincos64 in place of
+ * libm.  Observations handed to the policy are float32(state) as in the reference (neural_network.py:22). */
+static int cartpole_step64(double st[4], int action)
+{
+    const double gravity = 9.8, masscart = 1.0, masspole = 0.1, length = 0.5, force_mag = 10.0, tau = 0.02;
+    const double total_mass = masspole + masscart, polemass_length = masspole * length;
+    const double x = st[0], x_dot = st[1], theta = st[2], theta_dot = st[3];
+    const double force = action == 1 ? force_mag : -force_mag;
+    double sintheta, costheta;
+    o_sincos64(theta, &sintheta, &costheta);
+    const double temp = (force + ((polemass_length * (theta_dot * theta_dot)) * sintheta)) / total_mass;
+    const double thetaacc = ((gravity * sintheta) - (costheta * temp)) /
+                            (length * ((4.0 / 3.0) - ((masspole * (costheta * costheta)) / total_mass)));
+    const double xacc = temp - (((polemass_length * thetaacc) * costheta) / total_mass);
+    double nx = x + tau * x_dot, nxd = x_dot + tau * xacc, nth = theta + tau * theta_dot, nthd = theta_dot + tau * thetaacc;
+    const double lim = 1.0e4;                       /* only reachable after termination (fixed-length mode) */
+    nx = nx < -lim ? -lim : (nx > lim ? lim : nx);
+    nxd = nxd < -lim ? -lim : (nxd > lim ? lim : nxd);
+    nth = nth < -lim ? -lim : (nth > lim ? lim : nth);
+    nthd = nthd < -lim ? -lim : (nthd > lim ? lim : nthd);
+    st[0] = nx; st[1] = nxd; st[2] = nth; st[3] = nthd;
+    const double thr = 12 * 2 * 3.141592653589793 / 360;
+    return (nx < -2.4) | (nx > 2.4) | (nth < -thr) | (nth > thr);
+}
+
 /*
  * Standalone SoA env step over n envs (the unit the device K3 kernel is checked against).
  * status word: bits 0..30 = steps taken so far, bit 31 = done.
@@ -360,9 +386,29 @@ void o_cartpole_step_soa(int n, int mode, int max_step, float *x, float *xd, flo
  *   ep_return [N,E] f64 per-episode undiscounted return;  ep_steps [N,E] steps taken
  *   fitness   [N]   f32
  */
+static void rollout_cartpole_impl(int physics64, int S, int A, int discrete, int gru, int N, int E, int max_step, int mode,
+                                  uint32_t obs_mask, const float *theta, const float *init, int init_per_offspring,
+                                  double *ep_return, int32_t *ep_steps, float *fitness);
+
 void o_rollout_cartpole(int S, int A, int discrete, int gru, int N, int E, int max_step, int mode,
                         uint32_t obs_mask, const float *theta, const float *init, int init_per_offspring,
                         double *ep_return, int32_t *ep_steps, float *fitness)
+{
+    rollout_cartpole_impl(0, S, A, discrete, gru, N, E, max_step, mode, obs_mask, theta, init, init_per_offspring,
+                          ep_return, ep_steps, fitness);
+}
+
+void o_rollout_cartpole64(int S, int A, int discrete, int gru, int N, int E, int max_step, int mode,
+                          uint32_t obs_mask, const float *theta, const float *init, int init_per_offspring,
+                          double *ep_return, int32_t *ep_steps, float *fitness)
+{
+    rollout_cartpole_impl(1, S, A, discrete, gru, N, E, max_step, mode, obs_mask, theta, init, init_per_offspring,
+                          ep_return, ep_steps, fitness);
+}
+
+static void rollout_cartpole_impl(int physics64, int S, int A, int discrete, int gru, int N, int E, int max_step, int mode,
+                                  uint32_t obs_mask, const float *theta, const float *init, int init_per_offspring,
+                                  double *ep_return, int32_t *ep_steps, float *fitness)
 {
     const int P = o_param_count(S, A, gru);
     for (int i = 0; i < N; ++i) {
@@ -371,6 +417,7 @@ void o_rollout_cartpole(int S, int A, int discrete, int gru, int N, int E, int m
         for (int e = 0; e < E; ++e) {
             const float *s0 = init + ((size_t)(init_per_offspring ? i : 0) * E + e) * 4;
             float st[4] = {s0[0], s0[1], s0[2], s0[3]};
+            double st64[4] = {s0[0], s0[1], s0[2], s0[3]};
             float h[SES_H] = {0};
             float logits[SES_MAX_A], act[SES_MAX_A];
             double ret = 0.0;
@@ -378,9 +425,12 @@ void o_rollout_cartpole(int S, int A, int discrete, int gru, int N, int E, int m
             for (int t = 0; t < max_step; ++t) {
                 if (!alive && mode == MODE_EPISODIC) break;
                 float obs[4];
-                for (int k = 0; k < 4; ++k) obs[k] = ((obs_mask >> k) & 1u) ? 0.0f : st[k];
+                for (int k = 0; k < 4; ++k) {
+                    const float sv = physics64 ? (float)st64[k] : st[k];
+                    obs[k] = ((obs_mask >> k) & 1u) ? 0.0f : sv;
+                }
                 const int a = policy_forward(&v, S, A, discrete, gru, obs, h, logits, act);
-                const int term = cartpole_step(st, a);
+                const int term = physics64 ? cartpole_step64(st64, a) : cartpole_step(st, a);
                 if (alive) {
                     ret += 1.0;
                     steps += 1;

@@ -1,7 +1,8 @@
 """build_env / build_network / build_loop with the reference's signatures and YAML keys (builder.py:10-86).
 
 Optional keys (all default to reference behaviour): strategy.noise ("philox" | "numpy"),
-strategy.seed, env.seed, env.shared_init, env.n_agents (simple_spread: 2 like the reference, or 3).
+strategy.seed, env.seed, env.shared_init, env.n_agents (simple_spread: 2 like the reference, or 3),
+env.physics ("float32" | "float64": gym-order float64 CartPole dynamics).
 """
 from envs.gym_wrapper import GymWrapper
 from envs.pettingzoo_wrapper import PettingzooWrapper
@@ -20,7 +21,7 @@ _STRATEGIES = {
 def build_env(config):
     if config["name"] in _PETTINGZOO:
         return PettingzooWrapper(config["name"], config["max_step"], n_agents=config.get("n_agents", 2))
-    return GymWrapper(config["name"], config["max_step"], config["pomdp"])
+    return GymWrapper(config["name"], config["max_step"], config["pomdp"], physics=config.get("physics", "float32"))
 
 
 def build_network(config):

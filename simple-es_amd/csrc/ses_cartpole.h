@@ -65,4 +65,35 @@ SES_DEV bool cartpole_step(CartPoleState &s, int action)
     return cartpole_post(s, p, action);
 }
 
+// Gym-order float64 dynamics ("physics64"): the statements of gym's cartpole.py step() one by one, every
+// operation a separately rounded IEEE double operation, with sincos64_ in place of libm.  Slower (f64 VALU is
+// half rate) and not the benchmark path; it exists to show how much of the fp32-vs-gym deviation is precision:
+// agreement of per-offspring returns with a gym-faithful float64 env rises from 94.9 % (fp32) to 99.2 %, the rest
+// is libm's pow()/sin()/cos() differing from any restatement in the last ulp.
+struct CartPoleState64 {
+    double x, xd, th, thd;
+};
+
+SES_DEV bool cartpole_step64(CartPoleState64 &s, int action)
+{
+    const double gravity = 9.8, masscart = 1.0, masspole = 0.1, length = 0.5, force_mag = 10.0, tau = 0.02;
+    const double total_mass = masspole + masscart, polemass_length = masspole * length;
+    const double force = action == 1 ? force_mag : -force_mag;
+    double sintheta, costheta;
+    sincos64_(s.th, sintheta, costheta);
+    const double temp = (force + ((polemass_length * (s.thd * s.thd)) * sintheta)) / total_mass;
+    const double thetaacc = ((gravity * sintheta) - (costheta * temp)) /
+                            (length * ((4.0 / 3.0) - ((masspole * (costheta * costheta)) / total_mass)));
+    const double xacc = temp - (((polemass_length * thetaacc) * costheta) / total_mass);
+    double nx = s.x + tau * s.xd, nxd = s.xd + tau * xacc, nth = s.th + tau * s.thd, nthd = s.thd + tau * thetaacc;
+    const double lim = 1.0e4;
+    nx = nx < -lim ? -lim : (nx > lim ? lim : nx);
+    nxd = nxd < -lim ? -lim : (nxd > lim ? lim : nxd);
+    nth = nth < -lim ? -lim : (nth > lim ? lim : nth);
+    nthd = nthd < -lim ? -lim : (nthd > lim ? lim : nthd);
+    s.x = nx; s.xd = nxd; s.th = nth; s.thd = nthd;
+    const double thr = 12 * 2 * 3.141592653589793 / 360;
+    return (nx < -2.4) | (nx > 2.4) | (nth < -thr) | (nth > thr);
+}
+
 }  // namespace ses

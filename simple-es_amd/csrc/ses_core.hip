@@ -94,6 +94,8 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
                         cfg->num_action == 5 && cfg->discrete_action && !cfg->gru,
                     "ses_create: simple_spread needs n_agents in {2,3}, num_state=6*n_agents, num_action=5, "
                     "discrete_action=1, gru=0");
+    SES_REQUIRE(cfg->physics64 == 0 || (cfg->physics64 == 1 && cfg->env_id == SES_ENV_CARTPOLE),
+                "ses_create: physics64 is a CartPole rollout option");
     int ndev = ses_device_count();
     if (ndev <= 0) return ses::set_error(SES_ERR_NO_DEVICE, "ses_create: no HIP device visible");
     SES_REQUIRE(cfg->device >= 0 && cfg->device < ndev, "ses_create: device %d not in [0,%d)", cfg->device, ndev);

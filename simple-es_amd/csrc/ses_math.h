@@ -115,6 +115,36 @@ SES_DEV void sincos_(float x, float &s_out, float &c_out)
     c_out = ((q + 1) & 2) ? -cv : cv;
 }
 
+// double-precision sin/cos for the gym-order float64 CartPole (Cephes sin.c coefficients, Cody-Waite by pi/2)
+SES_DEV void sincos64_(double x, double &s_out, double &c_out)
+{
+    const double k = __builtin_rint(x * 0x1.45f306dc9c883p-1);
+    double r = __builtin_fma(k, -0x1.921fb544p+0, x);
+    r = __builtin_fma(k, -0x1.0b4611a6p-34, r);
+    r = __builtin_fma(k, -0x1.3198a2e037073p-69, r);
+    const double z = r * r;
+    double ps = 1.58962301576546568060E-10;
+    ps = __builtin_fma(ps, z, -2.50507477628578072866E-8);
+    ps = __builtin_fma(ps, z, 2.75573136213857245213E-6);
+    ps = __builtin_fma(ps, z, -1.98412698295895385996E-4);
+    ps = __builtin_fma(ps, z, 8.33333333332211858878E-3);
+    ps = __builtin_fma(ps, z, -1.66666666666666307295E-1);
+    const double s = __builtin_fma(ps * z, r, r);
+    double pc = -1.13585365213876817300E-11;
+    pc = __builtin_fma(pc, z, 2.08757008419747316778E-9);
+    pc = __builtin_fma(pc, z, -2.75573141792967388112E-7);
+    pc = __builtin_fma(pc, z, 2.48015872888517045348E-5);
+    pc = __builtin_fma(pc, z, -1.38888888888730564116E-3);
+    pc = __builtin_fma(pc, z, 4.16666666666665929218E-2);
+    const double c = __builtin_fma(pc * z, z, __builtin_fma(-0.5, z, 1.0));
+    const double kc = k < -1.0e9 ? -1.0e9 : (k > 1.0e9 ? 1.0e9 : k);
+    const int32_t q = (int32_t)kc;
+    const double sv = (q & 1) ? c : s;
+    const double cv = (q & 1) ? s : c;
+    s_out = (q & 2) ? -sv : sv;
+    c_out = ((q + 1) & 2) ? -cv : cv;
+}
+
 // natural log, normal positive inputs
 SES_DEV float log_(float x)
 {

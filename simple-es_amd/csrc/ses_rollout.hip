@@ -23,8 +23,52 @@ namespace ses {
 // between workgroups, so no XCD-aware remap is needed.
 // All state (4 floats of physics, the lane's slice of the weights, step counter) stays in VGPRs for
 // the whole episode; HBM is touched once at the start (theta row, initial state) and once at the end.
+// fp32 (default, folded constants) or gym-order float64 dynamics behind one interface
+template <bool PHYS64>
+struct CartPoleSim;
+
+template <>
+struct CartPoleSim<false> {
+    CartPoleState st;
+    CartPolePre pre;
+    __device__ __forceinline__ void init(const float *s0) { st = CartPoleState{s0[0], s0[1], s0[2], s0[3]}; }
+    __device__ __forceinline__ void observe(float (&o)[4]) const { o[0] = st.x; o[1] = st.xd; o[2] = st.th; o[3] = st.thd; }
+    __device__ __forceinline__ void prepare() { pre = cartpole_pre(st); }   // action-independent half
+    __device__ __forceinline__ bool advance(int action, bool keep_old)
+    {
+        CartPoleState ns = st;
+        const bool term = cartpole_post(ns, pre, action);
+        st.x = keep_old ? st.x : ns.x;
+        st.xd = keep_old ? st.xd : ns.xd;
+        st.th = keep_old ? st.th : ns.th;
+        st.thd = keep_old ? st.thd : ns.thd;
+        return term;
+    }
+};
+
+template <>
+struct CartPoleSim<true> {
+    CartPoleState64 st;
+    __device__ __forceinline__ void init(const float *s0) { st = CartPoleState64{s0[0], s0[1], s0[2], s0[3]}; }
+    __device__ __forceinline__ void observe(float (&o)[4]) const
+    {
+        o[0] = (float)st.x; o[1] = (float)st.xd; o[2] = (float)st.th; o[3] = (float)st.thd;   // neural_network.py:22
+    }
+    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ bool advance(int action, bool keep_old)
+    {
+        CartPoleState64 ns = st;
+        const bool term = cartpole_step64(ns, action);
+        st.x = keep_old ? st.x : ns.x;
+        st.xd = keep_old ? st.xd : ns.xd;
+        st.th = keep_old ? st.th : ns.th;
+        st.thd = keep_old ? st.thd : ns.thd;
+        return term;
+    }
+};
+
 // One wave's share of the rollout: envs [env0 + wave_local_index ...), LPE lanes per env.
-template <int LPE, bool FIXED_LENGTH>
+template <int LPE, bool FIXED_LENGTH, bool PHYS64 = false>
 __device__ __forceinline__ void rollout_cartpole_mlp_body(const TanhEntry *tanh_tab, long long lane_index, int env0,
                                                           const float *__restrict__ theta,
                                                           const float *__restrict__ init, int init_per_offspring,
@@ -43,7 +87,8 @@ __device__ __forceinline__ void rollout_cartpole_mlp_body(const TanhEntry *tanh_
     net.load(theta + (size_t)row * P, sub);
 
     const float *s0 = init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 4;
-    CartPoleState st{s0[0], s0[1], s0[2], s0[3]};
+    CartPoleSim<PHYS64> sim;
+    sim.init(s0);
     int steps = 0;
     bool alive = true;
 
@@ -52,23 +97,16 @@ __device__ __forceinline__ void rollout_cartpole_mlp_body(const TanhEntry *tanh_
             if (__ballot(alive) == 0ull) break;  // wave-uniform: every env of this wave is done
         }
         float obs[4];
-        obs[0] = (obs_mask & 1u) ? 0.0f : st.x;
-        obs[1] = (obs_mask & 2u) ? 0.0f : st.xd;
-        obs[2] = (obs_mask & 4u) ? 0.0f : st.th;
-        obs[3] = (obs_mask & 8u) ? 0.0f : st.thd;
+        sim.observe(obs);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) obs[k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
         float logits[2];
         typename MlpSlice<4, 2, LPE>::Pending pending;
         net.begin(tanh_tab, obs, pending);                 // fc1 + tanh table reads in flight ...
-        const CartPolePre pre = cartpole_pre(st);          // ... next to the action-independent half of the physics
+        sim.prepare();                                     // ... next to the action-independent half of the physics
         net.finish(pending, logits);
         const int action = argmax_first<2>(logits);
-        CartPoleState ns = st;
-        const bool term = cartpole_post(ns, pre, action);
-        const bool advance = FIXED_LENGTH ? true : alive;  // episodic: a finished env is frozen
-        st.x = advance ? ns.x : st.x;
-        st.xd = advance ? ns.xd : st.xd;
-        st.th = advance ? ns.th : st.th;
-        st.thd = advance ? ns.thd : st.thd;
+        const bool term = sim.advance(action, FIXED_LENGTH ? false : !alive);  // episodic: a finished env is frozen
         const int nsteps = steps + 1;
         const bool finished = term | (nsteps >= max_step);
         steps = alive ? nsteps : steps;
@@ -80,7 +118,7 @@ __device__ __forceinline__ void rollout_cartpole_mlp_body(const TanhEntry *tanh_
     }
 }
 
-template <int LPE, bool FIXED_LENGTH, int BLOCK>
+template <int LPE, bool FIXED_LENGTH, int BLOCK, bool PHYS64 = false>
 __global__ __launch_bounds__(BLOCK) void k_rollout_cartpole_mlp(const float *__restrict__ theta,
                                                              const float *__restrict__ init, int init_per_offspring,
                                                              int n_rows, int E, int P, int max_step,
@@ -89,7 +127,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_cartpole_mlp(const float *__r
 {
     __shared__ TanhEntry tanh_tab[SES_TANH_N];
     stage_tanh_table(tanh_tab);
-    rollout_cartpole_mlp_body<LPE, FIXED_LENGTH>(tanh_tab, (long long)blockIdx.x * BLOCK + threadIdx.x, 0, theta, init,
+    rollout_cartpole_mlp_body<LPE, FIXED_LENGTH, PHYS64>(tanh_tab, (long long)blockIdx.x * BLOCK + threadIdx.x, 0, theta, init,
                                                  init_per_offspring, n_rows * E, E, P, max_step, obs_mask, ep_return,
                                                  ep_steps);
 }
@@ -206,6 +244,33 @@ struct CartPoleLs {
         const int action = argmax_first<A>(logits);
         CartPoleState ns = s.st;
         done = cartpole_step(ns, action);
+        s.st.x = freeze ? s.st.x : ns.x;
+        s.st.xd = freeze ? s.st.xd : ns.xd;
+        s.st.th = freeze ? s.st.th : ns.th;
+        s.st.thd = freeze ? s.st.thd : ns.thd;
+        return 1.0f;
+    }
+};
+
+struct CartPoleLs64 {
+    static constexpr int S = 4, A = 2, INIT_W = 4;
+    struct State {
+        CartPoleState64 st;
+    };
+    __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u)
+    {
+        s.st = CartPoleState64{u[0], u[1], u[2], u[3]};
+    }
+    __device__ static __forceinline__ void observe(const State &s, float (&obs)[S])
+    {
+        obs[0] = (float)s.st.x; obs[1] = (float)s.st.xd; obs[2] = (float)s.st.th; obs[3] = (float)s.st.thd;
+    }
+    __device__ static __forceinline__ float step(State &s, const float (&logits)[A], const TanhEntry *, bool freeze,
+                                                 bool &done)
+    {
+        const int action = argmax_first<A>(logits);
+        CartPoleState64 ns = s.st;
+        done = cartpole_step64(ns, action);
         s.st.x = freeze ? s.st.x : ns.x;
         s.st.xd = freeze ? s.st.xd : ns.xd;
         s.st.th = freeze ? s.st.th : ns.th;
@@ -727,6 +792,35 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
         else
             hipLaunchKernelGGL((k_rollout_spread_mlp<3>), dim3(blocks), dim3(64), 0, h->stream, theta, init,
                                init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, epr);
+    } else if (h->cfg.physics64) {
+        // gym-order float64 dynamics: GRU lockstep or MLP at 4 / 8 lanes per env (parity option, not the bench path)
+        const int E = h->cfg.eval_ep_num, T = h->cfg.max_step;
+        const bool fixed = mode == SES_MODE_FIXED_LENGTH;
+        if (h->cfg.gru) {
+            const int blocks = ceil_div(n_rows, 4);
+            if (fixed)
+                hipLaunchKernelGGL((k_rollout_gru_lockstep<CartPoleLs64, true>), dim3(blocks), dim3(256), 0, h->stream,
+                                   theta, init, init_per_offspring, n_rows, E, h->P, T, h->obs_mask, epr, ep_steps);
+            else
+                hipLaunchKernelGGL((k_rollout_gru_lockstep<CartPoleLs64, false>), dim3(blocks), dim3(256), 0, h->stream,
+                                   theta, init, init_per_offspring, n_rows, E, h->P, T, h->obs_mask, epr, ep_steps);
+        } else if (pick_lanes_per_env(h, (long long)episodes) >= 8) {
+            const int blocks = ceil_div((long long)episodes * 8, 64);
+            if (fixed)
+                hipLaunchKernelGGL((k_rollout_cartpole_mlp<8, true, 64, true>), dim3(blocks), dim3(64), 0, h->stream, theta,
+                                   init, init_per_offspring, n_rows, E, h->P, T, h->obs_mask, epr, ep_steps);
+            else
+                hipLaunchKernelGGL((k_rollout_cartpole_mlp<8, false, 64, true>), dim3(blocks), dim3(64), 0, h->stream, theta,
+                                   init, init_per_offspring, n_rows, E, h->P, T, h->obs_mask, epr, ep_steps);
+        } else {
+            const int blocks = ceil_div((long long)episodes * 4, 64);
+            if (fixed)
+                hipLaunchKernelGGL((k_rollout_cartpole_mlp<4, true, 64, true>), dim3(blocks), dim3(64), 0, h->stream, theta,
+                                   init, init_per_offspring, n_rows, E, h->P, T, h->obs_mask, epr, ep_steps);
+            else
+                hipLaunchKernelGGL((k_rollout_cartpole_mlp<4, false, 64, true>), dim3(blocks), dim3(64), 0, h->stream, theta,
+                                   init, init_per_offspring, n_rows, E, h->P, T, h->obs_mask, epr, ep_steps);
+        }
     } else if (h->cfg.gru && !gru_sequential()) {
         const int blocks = ceil_div(n_rows, 4);
         if (mode == SES_MODE_FIXED_LENGTH)

@@ -15,7 +15,7 @@ SUPPORTED = {"CartPole-v1": dict(num_state=4, num_action=2, discrete=True, time_
 
 
 class GymWrapper:
-    def __init__(self, name, max_step=None, pomdp=False):
+    def __init__(self, name, max_step=None, pomdp=False, physics="float32"):
         if name not in SUPPORTED:
             raise NotImplementedError(
                 f"env {name!r} has no gfx950 kernel in this build (available: {sorted(SUPPORTED)}); "
@@ -24,6 +24,9 @@ class GymWrapper:
             raise AssertionError(f"{name} doesn't support POMDP.")
         self.name = name
         self.pomdp = bool(pomdp)
+        if physics not in ("float32", "float64"):
+            raise ValueError("env.physics must be 'float32' (default) or 'float64' (gym-order CartPole dynamics)")
+        self.physics64 = physics == "float64"
         self.spec = SUPPORTED[name]
         # YAML `max_step: None` is the STRING "None" in the reference (gym_wrapper.py:37); accept both.
         limit = self.spec["time_limit"]

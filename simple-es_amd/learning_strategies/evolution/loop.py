@@ -48,7 +48,7 @@ class ESLoop(BaseESLoop):
 
         self.dev = HipES(env.name, network.num_state, network.num_action, network.discrete_action, network.use_gru,
                          pomdp=env.pomdp, max_step=env.horizon, eval_ep_num=eval_ep_num,
-                         n_agents=getattr(env, "n_agents", 1))
+                         n_agents=getattr(env, "n_agents", 1), physics64=getattr(env, "physics64", False))
 
     # the rollout phase of one generation: Population -> float32[N] fitness (identical on every rank)
     def rollout(self, population):
@@ -108,7 +108,8 @@ def RolloutWorker(arguments):
     env, offspring, eval_ep_num = arguments
     model = next(iter(offspring.values()))
     dev = HipES(env.name, model.num_state, model.num_action, model.discrete_action, model.use_gru, pomdp=env.pomdp,
-                max_step=env.horizon, eval_ep_num=eval_ep_num, n_agents=getattr(env, "n_agents", 1))
+                max_step=env.horizon, eval_ep_num=eval_ep_num, n_agents=getattr(env, "n_agents", 1),
+                physics64=getattr(env, "physics64", False))
     theta = torch.from_numpy(model.flat()[None, :]).to(dev.device)
     init = dev.init_states_uniform(getattr(env, "seed_env", 0), getattr(env, "_episode", 0), 0, 1)
     env._episode = getattr(env, "_episode", 0) + 1

@@ -32,6 +32,7 @@ class SesConfig(ctypes.Structure):
         ("device", ctypes.c_int32),
         ("lanes_per_env", ctypes.c_int32),
         ("n_agents", ctypes.c_int32),
+        ("physics64", ctypes.c_int32),
     ]
 
 

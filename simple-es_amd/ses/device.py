@@ -29,7 +29,8 @@ class HipES:
     the reference's builder.build_env / build_network (builder.py:10-24)."""
 
     def __init__(self, env_name="CartPole-v1", num_state=4, num_action=2, discrete_action=True, gru=False,
-                 pomdp=False, max_step=500, eval_ep_num=5, device=None, lanes_per_env=0, n_agents=1):
+                 pomdp=False, max_step=500, eval_ep_num=5, device=None, lanes_per_env=0, n_agents=1,
+                 physics64=False):
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise SesError("no HIP device visible to torch: the simple-es hot path needs an MI355X "
@@ -52,7 +53,7 @@ class HipES:
         else:
             self.init_dim, self.init_range = 4, (-0.05, 0.05)
         cfg = SesConfig(self.env_id, self.S, self.A, int(self.discrete), int(self.gru), int(self.pomdp),
-                        self.max_step, self.E, int(device), int(lanes_per_env), self.n_agents)
+                        self.max_step, self.E, int(device), int(lanes_per_env), self.n_agents, int(bool(physics64)))
         self._lib = lib
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):

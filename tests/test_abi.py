@@ -59,7 +59,7 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
         HipES()
     # the raw ABI refuses as well
     lib = _lib.load()
-    cfg = _lib.SesConfig(0, 4, 2, 1, 0, 0, 500, 5, 0, 0)
+    cfg = _lib.SesConfig(0, 4, 2, 1, 0, 0, 500, 5, 0, 0, 1, 0)
     h = ctypes.c_void_p()
     rc = lib.ses_create(ctypes.byref(cfg), None, ctypes.byref(h))
     assert rc < 0 and lib.ses_last_error()

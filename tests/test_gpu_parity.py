@@ -396,14 +396,38 @@ def test_raw_c_abi_error_paths(es):
     r = torch.zeros(1, dtype=torch.int32, device="cuda")
     assert lib.ses_rank_center(h, p(f), 1, p(r), None) == -1                          # n - 1 = 0 divides in the reference
     assert lib.ses_elite_ids(h, p(r), 1, 2, p(r)) == -1                               # k > n
-    bad = _lib.SesConfig(0, 5, 2, 1, 0, 0, 500, 5, 0, 0, 1)                           # CartPole with num_state 5
+    bad = _lib.SesConfig(0, 5, 2, 1, 0, 0, 500, 5, 0, 0, 1, 0)                           # CartPole with num_state 5
     out = ctypes.c_void_p()
     assert lib.ses_create(ctypes.byref(bad), None, ctypes.byref(out)) == -1 and not out.value
-    bad = _lib.SesConfig(0, 4, 2, 1, 0, 0, 500, 5, 99, 0, 1)                          # device out of range
+    bad = _lib.SesConfig(0, 4, 2, 1, 0, 0, 500, 5, 99, 0, 1, 0)                          # device out of range
     assert lib.ses_create(ctypes.byref(bad), None, ctypes.byref(out)) == -1
-    bad = _lib.SesConfig(7, 4, 2, 1, 0, 0, 500, 5, 0, 0, 1)                           # unknown env
+    bad = _lib.SesConfig(7, 4, 2, 1, 0, 0, 500, 5, 0, 0, 1, 0)                           # unknown env
     assert lib.ses_create(ctypes.byref(bad), None, ctypes.byref(out)) == -1
     assert lib.ses_destroy(None) == 0
     # the handle is still healthy afterwards
     fit = es.rollout(torch.zeros(8, 226, device="cuda"), torch.zeros(5, 4, device="cuda"))
     assert fit.shape == (8,)
+
+
+@pytest.mark.parametrize("gru", [False, True])
+def test_physics64_rollout_bit_exact(golden_dir, gru):
+    """env.physics = float64: gym-order double-precision CartPole on the device == the C oracle, bit for bit."""
+    from ses import HipES
+    g = np.load(os.path.join(golden_dir, "g56_rollouts.npz"))
+    theta = g["g5gru_theta"] if gru else g["g5_theta"]
+    init = g["init_states"]
+    h = HipES("CartPole-v1", 4, 2, True, gru, pomdp=gru, max_step=500, eval_ep_num=5, physics64=True)
+    o_fit, _, o_steps = co.rollout_cartpole(theta, init, 5, 500, gru=gru, obs_mask=0b1010 if gru else 0, physics64=True)
+    for mode in (0, 1):
+        fit, _, steps = h.rollout(dev(theta), dev(init), mode=mode, want_episodes=True)
+        assert np.array_equal(host(steps), o_steps)
+        assert_bit_equal(host(fit), o_fit, "fitness")
+    if not gru:
+        agree = np.mean(np.abs(o_fit.astype(np.float64) - g["g5_returns_gym64"]) <= RETURN_TOL)
+        assert agree >= 0.99
+        # a larger population takes the 4-lanes-per-env variant
+        rng = np.random.RandomState(9)
+        big = (rng.randn(3000, 226) * 0.6).astype(np.float32)
+        assert_bit_equal(host(h.rollout(dev(big), dev(init))), co.rollout_cartpole(big, init, 5, 500, physics64=True)[0],
+                         "population of 3000")
+    h.close()
