@@ -14,6 +14,9 @@
  *   - every array argument is a CALLER-OWNED DEVICE pointer (e.g. torch tensor .data_ptr());
  *     the library never frees or reallocates it.  The handle owns only scratch.
  *   - calls enqueue work on the handle's HIP stream and return immediately; ses_sync() blocks.
+ *   - a handle is bound to one device and one stream and is NOT thread-safe: use it from one host thread at a
+ *     time (one handle per rank / per stream).  Calls may allocate handle-owned scratch on first use or when a
+ *     larger population arrives, so they are not hipGraph-capturable until the sizes have been seen once.
  *   - return value: SES_OK (0) or a negative SES_ERR_*; ses_last_error() gives a message
  *     (thread-local).  No C++ exception crosses the boundary.
  *   - "row" = one offspring's flat parameter vector, float32[P], in torch parameters() order

@@ -20,6 +20,7 @@ int set_error(int code, const char *fmt, ...)
 int ensure_episode_scratch(ses_handle *h, size_t episodes)
 {
     if (episodes <= h->ep_cap) return SES_OK;
+    if (h->ep_return || h->ep_steps) SES_HIP_TRY(hipStreamSynchronize(h->stream));   // kernels may still use the old buffers
     if (h->ep_return) SES_HIP_TRY(hipFree(h->ep_return));
     if (h->ep_steps) SES_HIP_TRY(hipFree(h->ep_steps));
     h->ep_return = nullptr;
