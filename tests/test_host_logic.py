@@ -97,3 +97,38 @@ def test_strategies_refuse_to_run_without_gpu():
     from ses import SesError
     with pytest.raises(SesError):
         openai_es(0.1, 0.999, 0.05, 16).init_offspring(GymEnvModel(4, 2, True, False), ["0"])
+
+
+def test_sweep_files_keep_reference_format_and_points_are_reproducible():
+    import random
+    sys.path.insert(0, SRC)
+    import sweep_main
+    for name in os.listdir(os.path.join(SRC, "sweep_config")):
+        spec = yaml.load(open(os.path.join(SRC, "sweep_config", name)), Loader=yaml.FullLoader)
+        assert {"program", "method", "metric", "parameters"} <= set(spec), name
+        assert spec["metric"]["name"] == "ep5_mean_reward"
+        for key, val in spec["parameters"].items():
+            assert set(val) in ({"value"}, {"values"}, {"min", "max"}), (name, key)
+            assert "--" + key in sweep_main_help(), key
+    spec = yaml.load(open(os.path.join(SRC, "sweep_config", "cartpole_genetic_grid.yaml")), Loader=yaml.FullLoader)
+    grid = list(sweep_main.trial_points(spec, None, random.Random(0)))
+    assert len(grid) == 6 and {(p["init_sigma"], p["elite_num"]) for p in grid} == {(s, k) for s in (0.5, 1.0, 2.0) for k in (2, 4)}
+    assert all(p["cfg_path"] == "conf/cartpole.yaml" and p["generation_num"] == 20 for p in grid)
+    spec = yaml.load(open(os.path.join(SRC, "sweep_config", "cartpole_openaies.yaml")), Loader=yaml.FullLoader)
+    a = list(sweep_main.trial_points(spec, 5, random.Random(3)))
+    b = list(sweep_main.trial_points(spec, 5, random.Random(3)))
+    assert a == b and len(a) == 5
+    assert all(0.001 <= p["learning_rate"] <= 0.2 and 0.05 <= p["init_sigma"] <= 1.0 and
+               p["sigma_decay"] in (0.999, 0.9999) for p in a)
+
+
+_HELP = {}
+
+
+def sweep_main_help():
+    if "out" not in _HELP:
+        out = subprocess.run([sys.executable, os.path.join(SRC, "sweep_main.py"), "--help"], capture_output=True,
+                             text=True, cwd=SRC, timeout=120)
+        assert out.returncode == 0, out.stderr
+        _HELP["out"] = out.stdout
+    return _HELP["out"]
