@@ -300,6 +300,7 @@ void o_policy_forward(int S, int A, int discrete, int gru, int n, const float *t
 #define CP_X_LIMIT 2.4f
 #define CP_THETA_LIMIT 0.20943951f /* 12 deg in rad, f32(12*2*pi/360) */
 #define CP_CLAMP 1.0e4f            /* state clamp (never active while an episode is alive) */
+#define CP_TH_CLAMP 0.75f          /* pole-angle clamp: past-terminal angles saturate at 43 deg (alive: |th| <= 12 deg) */
 
 static inline float clampf(float v, float lim) { return o_minf(o_maxf(v, -lim), lim); }
 
@@ -320,7 +321,7 @@ static int cartpole_step(float st[4], int action)
     const float xacc = o_fma(-CP_PML_OVER_MASS * thacc, c, temp);
     st[0] = clampf(o_fma(CP_TAU, xd, x), CP_CLAMP);
     st[1] = clampf(o_fma(CP_TAU, xacc, xd), CP_CLAMP);
-    st[2] = clampf(o_fma(CP_TAU, thd, th), CP_CLAMP);
+    st[2] = clampf(o_fma(CP_TAU, thd, th), CP_TH_CLAMP);
     st[3] = clampf(o_fma(CP_TAU, thacc, thd), CP_CLAMP);
     return (st[0] < -CP_X_LIMIT) | (st[0] > CP_X_LIMIT) | (st[2] < -CP_THETA_LIMIT) | (st[2] > CP_THETA_LIMIT);
 }

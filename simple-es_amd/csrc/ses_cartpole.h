@@ -18,6 +18,10 @@ constexpr float CP_TAU = 0.02f;
 constexpr float CP_X_LIMIT = 2.4f;
 constexpr float CP_THETA_LIMIT = 0.20943951f;  // 12 degrees
 constexpr float CP_CLAMP = 1.0e4f;             // never active while an episode is alive
+// The pole angle saturates at 43 degrees.  An episode ends at 12 degrees, so this never touches a live env; it
+// keeps the past-terminal states of the fixed-length (termination-masked) mode inside |th| < pi/4, where the
+// sin/cos argument reduction is the identity and cartpole_pre can skip it (see sincos_small_).
+constexpr float CP_TH_CLAMP = 0.75f;
 
 struct CartPoleState {
     float x, xd, th, thd;
@@ -31,14 +35,39 @@ struct CartPolePre {
     float sn, cs, q, gsn, den;
 };
 
-SES_DEV CartPolePre cartpole_pre(const CartPoleState &s)
+SES_DEV CartPolePre cartpole_pre_from(const CartPoleState &s, float sn, float cs)
 {
     CartPolePre p;
-    sincos_(s.th, p.sn, p.cs);
+    p.sn = sn;
+    p.cs = cs;
     p.q = CP_PML_OVER_MASS * (s.thd * s.thd);
     p.gsn = CP_GRAVITY * p.sn;
     p.den = fma_(CP_DEN_C1, p.cs * p.cs, CP_DEN_C0);
     return p;
+}
+
+// for callers that have established |th| <= SINCOS_SMALL_MAX (every state a previous step produced satisfies it)
+SES_DEV CartPolePre cartpole_pre_small(const CartPoleState &s)
+{
+    float sn, cs;
+    sincos_small_(s.th, sn, cs);
+    return cartpole_pre_from(s, sn, cs);
+}
+
+SES_DEV CartPolePre cartpole_pre(const CartPoleState &s)
+{
+    float sn, cs;
+#if defined(__HIPCC__)
+    // wave-uniform choice: every lane inside |th| <= 0.78 -> the reduction-free form, bit-identical there; a
+    // caller-supplied state outside it takes the general form.
+    if (__builtin_expect(__ballot(!(__builtin_fabsf(s.th) <= SINCOS_SMALL_MAX)) != 0ull, 0))
+        sincos_(s.th, sn, cs);
+    else
+        sincos_small_(s.th, sn, cs);
+#else
+    sincos_(s.th, sn, cs);
+#endif
+    return cartpole_pre_from(s, sn, cs);
 }
 
 // advances s in place; returns true when the NEW state is terminal
@@ -53,10 +82,10 @@ SES_DEV bool cartpole_post(CartPoleState &s, const CartPolePre &p, int action)
     const float xacc = fma_(-CP_PML_OVER_MASS * thacc, p.cs, temp);
     const float nx = clamp_sym(fma_(CP_TAU, s.xd, s.x), CP_CLAMP);
     const float nxd = clamp_sym(fma_(CP_TAU, xacc, s.xd), CP_CLAMP);
-    const float nth = clamp_sym(fma_(CP_TAU, s.thd, s.th), CP_CLAMP);
+    const float nth = clamp_sym(fma_(CP_TAU, s.thd, s.th), CP_TH_CLAMP);
     const float nthd = clamp_sym(fma_(CP_TAU, thacc, s.thd), CP_CLAMP);
     s.x = nx; s.xd = nxd; s.th = nth; s.thd = nthd;
-    return (nx < -CP_X_LIMIT) | (nx > CP_X_LIMIT) | (nth < -CP_THETA_LIMIT) | (nth > CP_THETA_LIMIT);
+    return (nx < -CP_X_LIMIT) || (nx > CP_X_LIMIT) || (nth < -CP_THETA_LIMIT) || (nth > CP_THETA_LIMIT);
 }
 
 SES_DEV bool cartpole_step(CartPoleState &s, int action)

@@ -72,6 +72,21 @@ SES_DEV int32_t tanh_index(float x, float &u)
     return (int32_t)t;
 }
 
+// same index / fraction from a pre-activation that already carries the factor 32 (the MLP kernels fold it into
+// W1 and b1 when they load them: a power-of-two scale commutes with every rounding of the fma chain unless an
+// intermediate is subnormal, |acc| < 2^-126, where the scaled chain keeps more bits of a value that is zero to
+// 1e-38 either way)
+SES_DEV int32_t tanh_index_scaled(float x32, float &u)
+{
+    const float t = min_(__builtin_fabsf(x32), SES_TANH_XMAX * SES_TANH_H_INV);
+#if defined(__HIPCC__)
+    u = __builtin_amdgcn_fractf(t);
+#else
+    u = t - __builtin_floorf(t);
+#endif
+    return (int32_t)t;
+}
+
 SES_DEV float tanh_eval(const TanhEntry &c, float u, float x)
 {
     float p = fma_(c.c3, u, c.c2);
@@ -113,6 +128,24 @@ SES_DEV void sincos_(float x, float &s_out, float &c_out)
     const float cv = (q & 1) ? s : c;
     s_out = (q & 2) ? -sv : sv;
     c_out = ((q + 1) & 2) ? -cv : cv;
+}
+
+// sincos_ restricted to |x| <= SINCOS_SMALL_MAX < pi/4: there k = rint(x * 2/pi) is zero, the Cody-Waite
+// reduction returns r = x exactly and the quadrant logic selects (s, c) unchanged, so the two polynomials on x
+// itself are sincos_(x) bit for bit (x = -0 gives sin = -0 where sincos_ gives +0; equal as numbers and in
+// every product or sum they enter).
+constexpr float SINCOS_SMALL_MAX = 0.78f;
+SES_DEV void sincos_small_(float r, float &s_out, float &c_out)
+{
+    const float z = r * r;
+    float ps = -1.9515295891e-4f;
+    ps = fma_(ps, z, 8.3321608736e-3f);
+    ps = fma_(ps, z, -1.6666654611e-1f);
+    s_out = fma_(ps * z, r, r);
+    float pc = 2.443315711809948e-5f;
+    pc = fma_(pc, z, -1.388731625493765e-3f);
+    pc = fma_(pc, z, 4.166664568298827e-2f);
+    c_out = fma_(pc * z, z, fma_(-0.5f, z, 1.0f));
 }
 
 // double-precision sin/cos for the gym-order float64 CartPole (Cephes sin.c coefficients, Cody-Waite by pi/2)

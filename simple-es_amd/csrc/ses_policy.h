@@ -49,8 +49,8 @@ struct MlpSlice {
     static constexpr int U = H / LPE;   // hidden units owned by this lane
     static constexpr int G = U / 4;     // fc2 groups owned by this lane
     static_assert(U % 4 == 0, "a lane owns whole fc2 groups");
-    float w1[U][S];
-    float b1[U];
+    float w1[U][S];   // times 32 (the tanh table's 1/h), see tanh_index_scaled
+    float b1[U];      // times 32
     float w2[A][U];
     float b2[A];
 
@@ -65,8 +65,8 @@ struct MlpSlice {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
-            for (int k = 0; k < S; ++k) w1[u][k] = pw1[(j0 + u) * S + k];
-            b1[u] = pb1[j0 + u];
+            for (int k = 0; k < S; ++k) w1[u][k] = SES_TANH_H_INV * pw1[(j0 + u) * S + k];
+            b1[u] = SES_TANH_H_INV * pb1[j0 + u];
         }
 #pragma unroll
         for (int a = 0; a < A; ++a) {
@@ -95,8 +95,8 @@ struct MlpSlice {
             float acc = b1[u];
 #pragma unroll
             for (int k = 0; k < S; ++k) acc = fma_(w1[u][k], obs[k], acc);
-            pd.pre[u] = acc;
-            idx[u] = tanh_index(acc, pd.frac[u]);
+            pd.pre[u] = acc;                                   // 32 * pre-activation: only its sign is used below
+            idx[u] = tanh_index_scaled(acc, pd.frac[u]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -152,6 +152,12 @@ __device__ __forceinline__ void stage_tanh_table(TanhEntry *lds)
         lds[i] = TanhEntry{v.x, v.y, v.z, v.w};
     }
     __syncthreads();
+}
+
+__device__ __forceinline__ int add_mask_bit(int v, unsigned long long mask)
+{
+    asm("v_addc_co_u32_e64 %0, vcc, %0, 0, %1" : "+v"(v) : "s"(mask) : "vcc");
+    return v;
 }
 
 template <int A>

@@ -33,7 +33,20 @@ struct CartPoleSim<false> {
     CartPolePre pre;
     __device__ __forceinline__ void init(const float *s0) { st = CartPoleState{s0[0], s0[1], s0[2], s0[3]}; }
     __device__ __forceinline__ void observe(float (&o)[4]) const { o[0] = st.x; o[1] = st.xd; o[2] = st.th; o[3] = st.thd; }
-    __device__ __forceinline__ void prepare() { pre = cartpole_pre(st); }   // action-independent half
+    // |pole angle| <= SINCOS_SMALL_MAX for this lane now -- and then for the whole episode (CP_TH_CLAMP)
+    __device__ __forceinline__ bool small_angle() const { return __builtin_fabsf(st.th) <= SINCOS_SMALL_MAX; }
+    template <bool SMALL>
+    __device__ __forceinline__ void prepare()                               // action-independent half
+    {
+        pre = SMALL ? cartpole_pre_small(st) : cartpole_pre(st);
+    }
+    // wave mask of the lanes whose CURRENT state is terminal (== what advance() just returned when nothing was
+    // frozen); two ballots of plain compares so that the mask is formed in SGPRs without a detour through a VGPR
+    __device__ __forceinline__ unsigned long long terminal_mask() const
+    {
+        return __builtin_amdgcn_ballot_w64(__builtin_fabsf(st.x) > CP_X_LIMIT) |
+               __builtin_amdgcn_ballot_w64(__builtin_fabsf(st.th) > CP_THETA_LIMIT);
+    }
     __device__ __forceinline__ bool advance(int action, bool keep_old)
     {
         CartPoleState ns = st;
@@ -54,7 +67,15 @@ struct CartPoleSim<true> {
     {
         o[0] = (float)st.x; o[1] = (float)st.xd; o[2] = (float)st.th; o[3] = (float)st.thd;   // neural_network.py:22
     }
+    __device__ __forceinline__ bool small_angle() const { return false; }
+    template <bool SMALL>
     __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ unsigned long long terminal_mask() const
+    {
+        const double thr = 12 * 2 * 3.141592653589793 / 360;
+        return __builtin_amdgcn_ballot_w64(__builtin_fabs(st.x) > 2.4) |
+               __builtin_amdgcn_ballot_w64(__builtin_fabs(st.th) > thr);
+    }
     __device__ __forceinline__ bool advance(int action, bool keep_old)
     {
         CartPoleState64 ns = st;
@@ -66,6 +87,43 @@ struct CartPoleSim<true> {
         return term;
     }
 };
+
+// The step loop of one wave.  MASKED: some observation components are zeroed (POMDP).  SMALL: every lane's pole
+// angle is inside |th| <= SINCOS_SMALL_MAX, so the sin/cos argument reduction is skipped (ses_cartpole.h).
+template <int LPE, bool FIXED_LENGTH, bool PHYS64, bool MASKED, bool SMALL>
+__device__ __forceinline__ void rollout_cartpole_mlp_loop(const TanhEntry *tanh_tab, const MlpSlice<4, 2, LPE> &net,
+                                                          CartPoleSim<PHYS64> &sim, int max_step, uint32_t obs_mask,
+                                                          int &steps)
+{
+    bool alive = true;
+    unsigned long long alive_mask = ~0ull;
+    for (int t = 0; t < max_step; ++t) {
+        if constexpr (!FIXED_LENGTH) {
+            if (__ballot(alive) == 0ull) break;  // wave-uniform: every env of this wave is done
+        }
+        float obs[4];
+        sim.observe(obs);
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) obs[k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
+        }
+        float logits[2];
+        typename MlpSlice<4, 2, LPE>::Pending pending;
+        net.begin(tanh_tab, obs, pending);                 // fc1 + tanh table reads in flight ...
+        sim.template prepare<SMALL>();                     // ... next to the action-independent half of the physics
+        net.finish(pending, logits);
+        const int action = argmax_first<2>(logits);
+        const bool term = sim.advance(action, FIXED_LENGTH ? false : !alive);  // episodic: a finished env is frozen
+        // (the horizon needs no test here: a live env reaches max_step exactly when the loop ends)
+        if constexpr (FIXED_LENGTH) {                      // the flag lives in SGPRs as a wave mask
+            steps = add_mask_bit(steps, alive_mask);
+            alive_mask &= ~sim.terminal_mask();
+        } else {                                           // per-lane flag: it also freezes the env
+            steps += (int)alive;
+            alive = alive & !term;
+        }
+    }
+}
 
 // One wave's share of the rollout: envs [env0 + wave_local_index ...), LPE lanes per env.
 template <int LPE, bool FIXED_LENGTH, bool PHYS64 = false>
@@ -90,28 +148,18 @@ __device__ __forceinline__ void rollout_cartpole_mlp_body(const TanhEntry *tanh_
     CartPoleSim<PHYS64> sim;
     sim.init(s0);
     int steps = 0;
-    bool alive = true;
-
-    for (int t = 0; t < max_step; ++t) {
-        if constexpr (!FIXED_LENGTH) {
-            if (__ballot(alive) == 0ull) break;  // wave-uniform: every env of this wave is done
-        }
-        float obs[4];
-        sim.observe(obs);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) obs[k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
-        float logits[2];
-        typename MlpSlice<4, 2, LPE>::Pending pending;
-        net.begin(tanh_tab, obs, pending);                 // fc1 + tanh table reads in flight ...
-        sim.prepare();                                     // ... next to the action-independent half of the physics
-        net.finish(pending, logits);
-        const int action = argmax_first<2>(logits);
-        const bool term = sim.advance(action, FIXED_LENGTH ? false : !alive);  // episodic: a finished env is frozen
-        const int nsteps = steps + 1;
-        const bool finished = term | (nsteps >= max_step);
-        steps = alive ? nsteps : steps;
-        alive = alive & !finished;
-    }
+    // Loop variants, chosen once per wave (both conditions are wave-uniform):
+    //  * fully observed envs (obs_mask == 0, a kernel argument) skip the four masking selects per step;
+    //  * when every lane starts inside |th| <= 0.78 -- resets are U(-0.05, 0.05) -- the angle stays there for the
+    //    whole episode (CP_TH_CLAMP) and the sin/cos argument reduction is skipped, bit-identically (sincos_small_);
+    //    a caller-supplied initial state outside that range runs the general loop.
+    const bool small = !PHYS64 && __ballot(!sim.small_angle()) == 0ull;
+    if (obs_mask == 0u && small)
+        rollout_cartpole_mlp_loop<LPE, FIXED_LENGTH, PHYS64, false, true>(tanh_tab, net, sim, max_step, obs_mask, steps);
+    else if (small)
+        rollout_cartpole_mlp_loop<LPE, FIXED_LENGTH, PHYS64, true, true>(tanh_tab, net, sim, max_step, obs_mask, steps);
+    else
+        rollout_cartpole_mlp_loop<LPE, FIXED_LENGTH, PHYS64, true, false>(tanh_tab, net, sim, max_step, obs_mask, steps);
     if (valid && sub == 0) {
         if (ep_return) ep_return[env] = (double)steps;  // CartPole reward is 1 per step incl. the terminal one
         if (ep_steps) ep_steps[env] = steps;

@@ -174,6 +174,29 @@ def _trunc_handle():
     return _TRUNC["h"]
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_env_step_wild_states_general_sincos_and_angle_clamp(es, mode):
+    """Caller-supplied states far outside the live region: pole angles beyond pi/4 take the general sin/cos
+    (argument reduction) instead of the small-angle form, and past-terminal angles saturate at 0.75 rad."""
+    n = 20000
+    rng = np.random.RandomState(77 + mode)
+    st = [rng.uniform(-3, 3, n).astype(np.float32), rng.uniform(-20, 20, n).astype(np.float32),
+          rng.uniform(-40, 40, n).astype(np.float32), rng.uniform(-60, 60, n).astype(np.float32)]
+    st[2][::7] = rng.uniform(-0.2, 0.2, st[2][::7].size).astype(np.float32)     # waves with mixed small / large angles
+    ret, status = np.zeros(n, np.float32), np.zeros(n, np.uint32)
+    d = [dev(a) for a in st]
+    d_ret, d_status = dev(ret), dev(status.view(np.int32))
+    for t in range(6):
+        action = rng.randint(0, 2, n).astype(np.int32)
+        co.cartpole_step_soa(mode, 500, st[0], st[1], st[2], st[3], action, ret, status)
+        es.env_step(d[0], d[1], d[2], d[3], dev(action), d_ret, d_status, mode=mode)
+    for k in range(4):
+        assert_bit_equal(host(d[k]), st[k], f"state[{k}]")
+    assert_bit_equal(host(d_ret), ret, "ret")
+    if mode == 1:
+        assert np.abs(st[2]).max() == np.float32(0.75)           # the clamp was active
+
+
 def test_env_step_unaligned_views_take_scalar_path(es):
     n = 1001
     rng = np.random.RandomState(3)
@@ -224,6 +247,30 @@ def test_rollout_per_offspring_init_and_pomdp(es):
     assert_bit_equal(fitp, o_fitp, "POMDP mask + max_step 200")
     assert not np.array_equal(fitp, np.minimum(fit, 200))
     hp.close()
+
+
+@pytest.mark.parametrize("lpe", [0, 4, 8])
+def test_rollout_wild_initial_states_take_the_general_loop(lpe):
+    """Initial pole angles outside |th| <= 0.78 (not a reset the env produces, but the ABI accepts any state):
+    such waves run the loop with the full sin/cos argument reduction; waves of ordinary resets run the
+    small-angle loop.  Both must agree with the oracle bit for bit, in both modes, with and without a mask."""
+    from ses import HipES
+    rng = np.random.RandomState(5)
+    n = 640
+    theta = (rng.randn(n, 226) * 0.8).astype(np.float32)
+    init = rng.uniform(-0.05, 0.05, (n, 5, 4)).astype(np.float32)
+    wild = rng.rand(n) < 0.3                                          # whole offspring, so some waves stay ordinary
+    init[wild, :, 2] = rng.uniform(-3.0, 3.0, (wild.sum(), 5)).astype(np.float32)
+    init[wild, :, 3] = (-init[wild, :, 2] / 0.02 + rng.uniform(-5, 5, (wild.sum(), 5))).astype(np.float32)  # swings back
+    for pomdp, mask in ((False, 0), (True, 0b1010)):
+        h = HipES("CartPole-v1", 4, 2, True, False, pomdp=pomdp, max_step=300, eval_ep_num=5, lanes_per_env=lpe)
+        o_fit, _, o_steps = co.rollout_cartpole(theta, init, 5, 300, obs_mask=mask)
+        assert (o_steps.reshape(n, 5)[wild] > 1).any()                # some wild starts survive the first step
+        for mode in (0, 1):
+            fit, _, ep_steps = h.rollout(dev(theta), dev(init), mode=mode, want_episodes=True)
+            assert np.array_equal(host(ep_steps), o_steps), (pomdp, mode)
+            assert_bit_equal(host(fit), o_fit, f"pomdp={pomdp} mode={mode}")
+        h.close()
 
 
 def test_rollout_edge_sizes(es):

@@ -29,6 +29,8 @@ void v_sig(const float* x, float* y, int n) { init(); for (int i = 0; i < n; i++
 void v_log(const float* x, float* y, int n) { for (int i = 0; i < n; i++) y[i] = ses::log_(x[i]); }
 void v_sin(const float* x, float* y, int n) { float c; for (int i = 0; i < n; i++) ses::sincos_(x[i], y[i], c); }
 void v_cos(const float* x, float* y, int n) { float s; for (int i = 0; i < n; i++) ses::sincos_(x[i], s, y[i]); }
+void v_sin_small(const float* x, float* y, int n) { float c; for (int i = 0; i < n; i++) ses::sincos_small_(x[i], y[i], c); }
+void v_cos_small(const float* x, float* y, int n) { float s; for (int i = 0; i < n; i++) ses::sincos_small_(x[i], s, y[i]); }
 void v_cp(float* st, const int* a, int* term, int n) { for (int i = 0; i < n; i++) {
   ses::CartPoleState s{st[4*i], st[4*i+1], st[4*i+2], st[4*i+3]}; term[i] = ses::cartpole_step(s, a[i]);
   st[4*i] = s.x; st[4*i+1] = s.xd; st[4*i+2] = s.th; st[4*i+3] = s.thd; } }
@@ -72,6 +74,21 @@ def test_device_math_equals_oracle_math_bitwise(libs):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), fn
     xl = np.abs(x[np.isfinite(x) & (x != 0)])
     assert np.array_equal(call(dev, "v_log", xl).view(np.uint32), call(ora, "v_log", xl).view(np.uint32))
+
+
+def test_small_angle_sincos_is_the_general_one_inside_its_range(libs):
+    """sincos_small_ (no argument reduction) == sincos_ == oracle for every |x| <= SINCOS_SMALL_MAX, which is where
+    cartpole_pre uses it; checked on all floats of a dense grid plus the range ends."""
+    dev, ora = libs
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(-0.78, 0.78, 2_000_000), rng.normal(0, 0.05, 500_000), rng.normal(0, 1e-6, 10_000),
+                        [0.78, -0.78, 0.75, -0.75, 0.20943951, 0.0, 1e-30, -1e-30]]).astype(np.float32)
+    x = x[np.abs(x) <= np.float32(0.78)]
+    x = x[x.view(np.uint32) != 0x80000000]          # -0.0: sin differs in the sign of zero only (documented)
+    for small, full in (("v_sin_small", "v_sin"), ("v_cos_small", "v_cos")):
+        a = call(dev, small, x)
+        assert np.array_equal(a.view(np.uint32), call(dev, full, x).view(np.uint32)), small
+        assert np.array_equal(a.view(np.uint32), call(ora, full, x).view(np.uint32)), small
 
 
 def test_device_cartpole_equals_oracle_bitwise(libs):
