@@ -94,6 +94,17 @@ SES_DEV bool cartpole_step(CartPoleState &s, int action)
     return cartpole_post(s, p, action);
 }
 
+// The same step with the general sin/cos unconditionally.  For kernels where the physics is a small part of the
+// step (the GRU rollouts): the per-step uniform branch of cartpole_pre cost them far more than the reduction it
+// skips (lockstep GRU rollout 2.96 ms with this form, 4.57 ms with the branch inside the gate loop's schedule).
+SES_DEV bool cartpole_step_general(CartPoleState &s, int action)
+{
+    float sn, cs;
+    sincos_(s.th, sn, cs);
+    const CartPolePre p = cartpole_pre_from(s, sn, cs);
+    return cartpole_post(s, p, action);
+}
+
 // Gym-order float64 dynamics ("physics64"): the statements of gym's cartpole.py step() one by one, every
 // operation a separately rounded IEEE double operation, with sincos64_ in place of libm.  Slower (f64 VALU is
 // half rate) and not the benchmark path; it exists to show how much of the fp32-vs-gym deviation is precision:

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_rollout_cartpole_gru(const float *__res
             net.forward(tanh_tab, obs, h, vec, lane, logits);
             const int action = argmax_first<2>(logits);
             CartPoleState ns = st;
-            const bool term = cartpole_step(ns, action);
+            const bool term = cartpole_step_general(ns, action);
             const bool advance = FIXED_LENGTH ? true : alive;
             st.x = advance ? ns.x : st.x;
             st.xd = advance ? ns.xd : st.xd;
@@ -291,7 +291,7 @@ struct CartPoleLs {
     {
         const int action = argmax_first<A>(logits);
         CartPoleState ns = s.st;
-        done = cartpole_step(ns, action);
+        done = cartpole_step_general(ns, action);
         s.st.x = freeze ? s.st.x : ns.x;
         s.st.xd = freeze ? s.st.xd : ns.xd;
         s.st.th = freeze ? s.st.th : ns.th;
