@@ -26,28 +26,34 @@ constexpr int GL_EB = 8;   // episodes per lockstep batch = owner slots per 8-la
 // cycles instead of 4 (SQ_LDS_IDX_ACTIVE), making the kernel LDS-bound.
 template <int S, int A>
 struct alignas(16) GruLockstepLds {
-    float a[GL_EB][32];      // fc1 activations
-    float h[GL_EB][32];      // hidden state
+    float ah[GL_EB][32][2];  // [k][0] fc1 activation a_k, [k][1] hidden state h_k: one b128 read = two (a, h) pairs
     float y[GL_EB][36];      // tanh(h') for fc2; 144-B rows: the 8 owner rows fall on 8 different bank groups
     float obs[GL_EB][8];     // observations (S <= 8), masked
     float w2[A][32];
     float b2[A];
 };
 
-// x = (lower: value for the upper half, upper: value for the lower half) -> exchanged halves
-__device__ __forceinline__ float swap_halves(float x, int kh)
+// p0 / p1: this lane's partial sums (its k-half) for the even / odd episode of a pair.  The lower half of the wave
+// finishes the even episode, the upper half the odd one.  v_permlane32_swap exchanges p0's upper half with p1's
+// lower half; afterwards p0 = (own partial | other half's partial) and p1 = (other | own), so p0 + p1 is
+// lower-k + upper-k of the episode each lane finishes: one swap and one add, no selects.
+__device__ __forceinline__ float pair_total(float p0, float p1)
 {
-    float a = x, b = x;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    // after the swap: a.upper = x.lower, b.lower = x.upper
-    return kh ? a : b;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(p0), "+v"(p1));
+    return p0 + p1;
 }
+
+// (input-side, hidden-side) halves of one gate row's contraction ride one v_pk_fma_f32: the weights
+// (W_ih[g][j][k], W_hh[g][j][k]) sit in a register pair, the operands (a_k, h_k) arrive as a pair from LDS, the two
+// partial sums are the pair's halves.  96 -> 48 contraction instructions per episode; each half is an ordinary
+// IEEE fma in the same k order, so the sums keep their bits.
+typedef float gl_v2f __attribute__((ext_vector_type(2)));
 
 template <int S, int A>
 struct GruLockstep {
     float w1[S], b1;
-    float wih[3][16], whh[3][16];
-    float bih[3], bhh[3];
+    gl_v2f w[3][16];         // {W_ih, W_hh}[g][j][16 kh + k]
+    gl_v2f b[3];             // {b_ih, b_hh}[g][j] on the lower half, 0 on the upper half
 
     __device__ __forceinline__ void load(const float *__restrict__ theta, int lane, GruLockstepLds<S, A> &lds)
     {
@@ -63,11 +69,9 @@ struct GruLockstep {
         for (int g = 0; g < 3; ++g) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                wih[g][k] = pih[(g * H + j) * H + 16 * kh + k];
-                whh[g][k] = phh[(g * H + j) * H + 16 * kh + k];
+                w[g][k] = gl_v2f{pih[(g * H + j) * H + 16 * kh + k], phh[(g * H + j) * H + 16 * kh + k]};
             }
-            bih[g] = kh ? 0.0f : pbi[g * H + j];
-            bhh[g] = kh ? 0.0f : pbh[g * H + j];
+            b[g] = kh ? gl_v2f{0.0f, 0.0f} : gl_v2f{pbi[g * H + j], pbh[g * H + j]};
         }
         p = pbh + 3 * H;
         if (kh == 0) {
@@ -93,50 +97,45 @@ struct GruLockstep {
             float acc = b1;
 #pragma unroll
             for (int k = 0; k < S; ++k) acc = fma_(w1[k], lds.obs[me][k], acc);
-            lds.a[me][j] = tanh_(tab, acc);
+            lds.ah[me][j][0] = tanh_(tab, acc);
         }
         wave_lds_sync();
         float hn[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            float part[2][6];
+            gl_v2f part[2][3];                             // [q][g] = {input-side, hidden-side} partial sums
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int e = 2 * p + q;
                 if (ODD && p == NP - 1 && q == 1) {
 #pragma unroll
-                    for (int g = 0; g < 6; ++g) part[q][g] = 0.0f;
+                    for (int g = 0; g < 3; ++g) part[q][g] = gl_v2f{0.0f, 0.0f};
                     continue;
                 }
                 // all 8 slice reads of this episode are issued before the first fma needs one of them
-                const float4 *va = reinterpret_cast<const float4 *>(&lds.a[e][16 * kh]);
-                const float4 *vh = reinterpret_cast<const float4 *>(&lds.h[e][16 * kh]);
-                float4 xa[4], xh[4];
+                const float4 *vx = reinterpret_cast<const float4 *>(&lds.ah[e][16 * kh][0]);
+                float4 x[8];
 #pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) { xa[c4] = va[c4]; xh[c4] = vh[c4]; }
+                for (int c2 = 0; c2 < 8; ++c2) x[c2] = vx[c2];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int g = 0; g < 3; ++g) { part[q][g] = bih[g]; part[q][3 + g] = bhh[g]; }
+                for (int g = 0; g < 3; ++g) part[q][g] = b[g];
 #pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    const float ea[4] = {xa[c4].x, xa[c4].y, xa[c4].z, xa[c4].w};
-                    const float eh[4] = {xh[c4].x, xh[c4].y, xh[c4].z, xh[c4].w};
+                for (int c2 = 0; c2 < 8; ++c2) {
+                    const gl_v2f x0 = {x[c2].x, x[c2].y}, x1 = {x[c2].z, x[c2].w};   // (a, h) at k = 2 c2, 2 c2 + 1
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
+                    for (int g = 0; g < 3; ++g) part[q][g] = __builtin_elementwise_fma(w[g][2 * c2], x0, part[q][g]);
 #pragma unroll
-                        for (int g = 0; g < 3; ++g) {
-                            part[q][g] = fma_(wih[g][4 * c4 + c], ea[c], part[q][g]);
-                            part[q][3 + g] = fma_(whh[g][4 * c4 + c], eh[c], part[q][3 + g]);
-                        }
+                    for (int g = 0; g < 3; ++g) part[q][g] = __builtin_elementwise_fma(w[g][2 * c2 + 1], x1, part[q][g]);
                 }
             }
             // I finish episode 2p + kh: keep my partial of it, hand over my partial of the other one
-            float tot[6];
+            float tot[6];                                  // 0..2 input side (r, z, n), 3..5 hidden side
 #pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                const float keep = kh ? part[1][g] : part[0][g];
-                const float give = kh ? part[0][g] : part[1][g];
-                tot[g] = keep + swap_halves(give, kh);   // lo + hi (lower half) / hi + lo (upper half): same bits
+            for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    tot[3 * s + g] = pair_total(s ? part[0][g].y : part[0][g].x, s ? part[1][g].y : part[1][g].x);
             }
             // r and z table lookups issued together
             const float pr = 0.5f * (tot[0] + tot[3]), pz = 0.5f * (tot[1] + tot[4]);
@@ -153,34 +152,36 @@ struct GruLockstep {
         for (int p = 0; p < NP; ++p) {
             const int me = 2 * p + kh;
             hreg[p] = hn[p];
-            lds.h[me][j] = hn[p];
+            lds.ah[me][j][1] = hn[p];
             lds.y[me][j] = tanh_(tab, hn[p]);
         }
         wave_lds_sync();
     }
 
-    // fc2 of episode e on its owner lane: canonical chain of 4 + tree over the 8 groups + bias
-    __device__ __forceinline__ void logits_of(const GruLockstepLds<S, A> &lds, int e, float (&logits)[A]) const
+    // fc2 of episode (lane & 7), spread over the 8 lanes that own it: lane l evaluates group (l >> 3) -- the
+    // canonical in-order chain over 4 consecutive hidden units -- and the balanced tree over the 8 groups is three
+    // exchange-and-add levels (lane bits 3, 4, 5): a DPP rotate inside the 16-lane row, then v_permlane16_swap and
+    // v_permlane32_swap on two copies, which leave (even | even) and (odd | odd) so that their sum is the pair
+    // total in every lane, even operand first.  Every lane of the slot ends with the same logits.
+    __device__ __forceinline__ void logits_of(const GruLockstepLds<S, A> &lds, int lane, float (&logits)[A]) const
     {
-        // group by group: one quad of y and one quad of every W2 row at a time (no 32-value register array)
-        float pg[A][8];
-        const float4 *vy = reinterpret_cast<const float4 *>(&lds.y[e][0]);
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const float4 y = vy[g];
-#pragma unroll
-            for (int o = 0; o < A; ++o) {
-                const float4 w = reinterpret_cast<const float4 *>(&lds.w2[o][0])[g];
-                float acc = w.x * y.x;
-                acc = fma_(w.y, y.y, acc);
-                acc = fma_(w.z, y.z, acc);
-                acc = fma_(w.w, y.w, acc);
-                pg[o][g] = acc;
-            }
-        }
+        const int e = lane & 7, grp = lane >> 3;
+        const float4 y = reinterpret_cast<const float4 *>(&lds.y[e][0])[grp];
 #pragma unroll
         for (int o = 0; o < A; ++o) {
-            logits[o] = (((pg[o][0] + pg[o][1]) + (pg[o][2] + pg[o][3])) + ((pg[o][4] + pg[o][5]) + (pg[o][6] + pg[o][7]))) + lds.b2[o];
+            const float4 w = reinterpret_cast<const float4 *>(&lds.w2[o][0])[grp];
+            float acc = w.x * y.x;
+            acc = fma_(w.y, y.y, acc);
+            acc = fma_(w.z, y.z, acc);
+            acc = fma_(w.w, y.w, acc);
+            acc = acc + dpp_mov<DPP_ROW_ROR8>(acc);                        // groups (0,1) (2,3) (4,5) (6,7)
+            float lo = acc, hi = acc;
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+            acc = lo + hi;                                                  // (01)+(23), (45)+(67)
+            lo = acc;
+            hi = acc;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+            logits[o] = (lo + hi) + lds.b2[o];
         }
     }
 };

@@ -33,6 +33,7 @@ __device__ __forceinline__ float dpp_mov(float v)
 constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm [1,0,3,2]
 constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm [2,3,0,1]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each group of 8
+constexpr int DPP_ROW_ROR8 = 0x128;        // lane i <- lane (i + 8) % 16 inside each row of 16
 
 // sum over the LPE lanes that share one env; every lane ends with the same bits
 template <int LPE>

@@ -363,7 +363,7 @@ __device__ __forceinline__ void gru_lockstep_batch(const TanhEntry *tanh_tab, Gr
     wave_lds_sync();
     if (lane < 32) {
 #pragma unroll
-        for (int e = 0; e < GL_EB; ++e) lds.h[e][lane] = 0.0f;
+        for (int e = 0; e < GL_EB; ++e) lds.ah[e][lane][1] = 0.0f;
     }
     double ret = 0.0;
     int steps = 0;
@@ -381,7 +381,7 @@ __device__ __forceinline__ void gru_lockstep_batch(const TanhEntry *tanh_tab, Gr
         wave_lds_sync();
         net.template step<NP, ODD>(tanh_tab, lds, hreg, lane);
         float logits[A];
-        net.logits_of(lds, slot, logits);
+        net.logits_of(lds, lane, logits);
         bool term;
         const bool freeze = FIXED_LENGTH ? false : !alive;
         const float r = EnvT::step(st, logits, tanh_tab, freeze, term);
