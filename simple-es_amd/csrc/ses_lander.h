@@ -30,34 +30,38 @@ constexpr float LL_SLEEP_V = 0.05f;
 constexpr int LL_SLEEP_STEPS = 25;
 constexpr uint64_t TAG_ENV_STEP = 2ull;
 
+// The terrain of an episode never changes, so reset() tabulates its 10 segments once -- {left height, rise,
+// normal x, normal y} per segment, with the very operations ll_terrain used to repeat at each of its 8 calls per step
+// (a sqrt and a division among them) -- into an LDS row owned by the env; ll_terrain is then one ds_read_b128.
+constexpr int LL_SEGMENTS = 10;
+
 struct LanderState {
     float x, y, vx, vy, ang, om;
     float prev_shaping;
     int has_prev, sleep, leg0, leg1;
-    float ty[11];
+    const float4 *seg;       // LDS: this env's segment table [LL_SEGMENTS]
     uint32_t key0, key1;
     int step;
 };
 
-__device__ __forceinline__ void ll_terrain(float x, const float (&ty)[11], float &h, float &nx, float &ny)
+__device__ __forceinline__ float4 ll_segment(float y0, float y1)
+{
+    const float d = y1 - y0;
+    const float slope = d * 0.5f;
+    const float inv = 1.0f / __builtin_sqrtf(fma_(slope, slope, 1.0f));
+    return float4{y0, d, -slope * inv, inv};
+}
+
+__device__ __forceinline__ void ll_terrain(float x, const float4 *seg, float &h, float &nx, float &ny)
 {
     float fk = __builtin_floorf(x * 0.5f);
     fk = min_(max_(fk, 0.0f), 9.0f);
     const int k = (int)fk;
     const float t = (x - 2.0f * fk) * 0.5f;
-    // register-resident table: select instead of a dynamic index (runtime-indexed arrays go to scratch)
-    float y0 = ty[0], y1 = ty[1];
-#pragma unroll
-    for (int j = 1; j < 10; ++j) {
-        y0 = k == j ? ty[j] : y0;
-        y1 = k == j ? ty[j + 1] : y1;
-    }
-    const float d = y1 - y0;
-    h = fma_(d, t, y0);
-    const float slope = d * 0.5f;
-    const float inv = 1.0f / __builtin_sqrtf(fma_(slope, slope, 1.0f));
-    nx = -slope * inv;
-    ny = inv;
+    const float4 e = seg[k];
+    h = fma_(e.y, t, e.x);
+    nx = e.z;
+    ny = e.w;
 }
 
 __device__ __forceinline__ void ll_obs(const LanderState &s, float (&obs)[8])
@@ -117,7 +121,7 @@ __device__ __forceinline__ float ll_step(LanderState &s, float a0, float a1, boo
         crx[i] = bx * cs - by * sn;
         cry[i] = bx * sn + by * cs;
         float h;
-        ll_terrain(s.x + crx[i], s.ty, h, cnx[i], cny[i]);
+        ll_terrain(s.x + crx[i], s.seg, h, cnx[i], cny[i]);
         cpen[i] = h - (s.y + cry[i]);
         active[i] = cpen[i] >= 0.0f;
     }
@@ -133,7 +137,7 @@ __device__ __forceinline__ float ll_step(LanderState &s, float a0, float a1, boo
     for (int k = 0; k < 6; ++k) {
         const float rx = HULL[k][0] * cs - HULL[k][1] * sn, ry = HULL[k][0] * sn + HULL[k][1] * cs;
         float h, nx, ny;
-        ll_terrain(s.x + rx, s.ty, h, nx, ny);
+        ll_terrain(s.x + rx, s.seg, h, nx, ny);
         crash = crash | (h - (s.y + ry) >= 0.0f);
     }
     if (active[0] | active[1]) {
@@ -194,16 +198,26 @@ __device__ __forceinline__ float ll_step(LanderState &s, float a0, float a1, boo
     return reward;
 }
 
-// reset from one row of 16 uniforms; like gym's reset() it ends with one no-op step
-__device__ __forceinline__ void ll_reset(LanderState &s, const float *__restrict__ u)
+// reset from one row of 16 uniforms; like gym's reset() it ends with one no-op step.
+// seg_row: LDS row of LL_SEGMENTS float4 owned by this env; every lane that simulates the env passes the same row
+// (they write identical values).  All lanes of the wave must call this together (wave-level LDS sync inside).
+__device__ __forceinline__ void ll_reset(LanderState &s, const float *__restrict__ u, float4 *seg_row)
 {
-    float height[12];
+    float height[12], ty[11];
 #pragma unroll
     for (int i = 0; i < 12; ++i) height[i] = u[2 + i] * (LL_H * 0.5f);
 #pragma unroll
     for (int i = 3; i <= 7; ++i) height[i] = LL_HELIPAD_Y;
 #pragma unroll
-    for (int i = 0; i < 11; ++i) s.ty[i] = 0.33f * ((height[i == 0 ? 11 : i - 1] + height[i]) + height[i + 1]);
+    for (int i = 0; i < 11; ++i) ty[i] = 0.33f * ((height[i == 0 ? 11 : i - 1] + height[i]) + height[i + 1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // earlier readers of the row are done
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < LL_SEGMENTS; ++k) seg_row[k] = ll_segment(ty[k], ty[k + 1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    s.seg = seg_row;
     s.x = LL_W * 0.5f;
     s.y = LL_H;
     s.vx = (fma_(u[0], 2.0f, -1.0f) * 1000.0f) * LL_INV_MASS * LL_DT;

@@ -332,7 +332,11 @@ struct LanderLs {
     struct State {
         LanderState st;
     };
-    __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u) { ll_reset(s.st, u); }
+    __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u)
+    {
+        __shared__ float4 seg[4][GL_EB][LL_SEGMENTS];          // one terrain table per (wave, episode slot)
+        ll_reset(s.st, u, seg[threadIdx.x >> 6][threadIdx.x & 7]);
+    }
     __device__ static __forceinline__ void observe(const State &s, float (&obs)[S]) { ll_obs(s.st, obs); }
     __device__ static __forceinline__ float step(State &s, const float (&logits)[A], const TanhEntry *tab, bool freeze,
                                                  bool &done)
@@ -449,6 +453,7 @@ __global__ __launch_bounds__(256) void k_rollout_lander(const float *__restrict_
     constexpr int S = 8, A = 4, LPE = 8;
     __shared__ TanhEntry tanh_tab[SES_TANH_N];
     __shared__ __attribute__((aligned(16))) float vecs[4][64];
+    __shared__ float4 seg[256 / LPE][LL_SEGMENTS];                // terrain tables: GRU one per wave, MLP one per env
     stage_tanh_table(tanh_tab);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if constexpr (GRU) {
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(256) void k_rollout_lander(const float *__restrict_
         float *vec = vecs[wave];
         for (int ep = 0; ep < E; ++ep) {
             LanderState st;
-            ll_reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 16);
+            ll_reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 16, seg[wave]);
             float h = 0.0f;
             wave_lds_sync();
             if (lane < 32) vec[32 + lane] = 0.0f;
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(256) void k_rollout_lander(const float *__restrict_
         MlpSlice<S, A, LPE> net;
         net.load(theta + (size_t)row * P, sub);
         LanderState st;
-        ll_reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 16);
+        ll_reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 16, seg[threadIdx.x / LPE]);
         double ret = 0.0;
         int steps = 0;
         bool done = false;

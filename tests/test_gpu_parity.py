@@ -273,6 +273,23 @@ def test_rollout_wild_initial_states_take_the_general_loop(lpe):
         h.close()
 
 
+@pytest.mark.parametrize("n", [1638, 1639, 1640, 2049, 9830, 9831])
+def test_rollout_split_boundaries(n):
+    """Population sizes on both sides of the launch heuristics (pure LPE-8 below 8192 episodes, the mixed LPE-8 + LPE-4
+    split up to 49 152, pure LPE-4 above): the ragged last waves of each part must still land on the oracle's bits."""
+    from ses import HipES
+    rng = np.random.RandomState(n)
+    theta = (rng.randn(n, 226) * 0.6).astype(np.float32)
+    init = rng.uniform(-0.05, 0.05, (n, 5, 4)).astype(np.float32)
+    h = HipES("CartPole-v1", 4, 2, True, False, max_step=40, eval_ep_num=5)
+    o_fit, _, o_steps = co.rollout_cartpole(theta, init, 5, 40)
+    for mode in (0, 1):
+        fit, _, ep_steps = h.rollout(dev(theta), dev(init), mode=mode, want_episodes=True)
+        assert np.array_equal(host(ep_steps), o_steps), (n, mode)
+        assert_bit_equal(host(fit), o_fit, f"n={n} mode={mode}")
+    h.close()
+
+
 def test_rollout_edge_sizes(es):
     """1 offspring, ragged tail of a wave, zero network (action 0 forever)."""
     init = np.random.RandomState(0).uniform(-0.05, 0.05, (5, 4)).astype(np.float32)
