@@ -162,16 +162,20 @@ def main():
     }
     if rank == 0:
         # per-kernel view of one generation (rank 0, HIP events on the launch stream)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        samples = []
         torch.cuda.synchronize()
-        ev[0].record()
-        es.perturb(mu, state["sigma"], seed, 10 ** 6, first, n_local, out=theta)
-        ev[1].record()
-        es.rollout(theta, init, mode=MODE_FIXED_LENGTH, fitness=fit_local)
-        ev[2].record()
-        ev[2].synchronize()
-        roll_ms = ev[1].elapsed_time(ev[2])
-        result["rollout_kernel"] = {"ms": roll_ms, "perturb_ms": ev[0].elapsed_time(ev[1]),
+        for rep in range(9):                                   # median of 9 back-to-back generations' kernels
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+            es.perturb(mu, state["sigma"], seed, 10 ** 6 + rep, first, n_local, out=theta)
+            ev[1].record()
+            es.rollout(theta, init, mode=MODE_FIXED_LENGTH, fitness=fit_local)
+            ev[2].record()
+            ev[2].synchronize()
+            samples.append((ev[1].elapsed_time(ev[2]), ev[0].elapsed_time(ev[1])))
+        samples.sort()
+        roll_ms, perturb_ms = samples[len(samples) // 2]
+        result["rollout_kernel"] = {"ms": roll_ms, "perturb_ms": perturb_ms,
                                     "env_steps_per_s_one_gpu": n_local * E * T / (roll_ms * 1e-3),
                                     "bound": "valu-issue/latency (state and weights in VGPRs, no HBM traffic in the loop)"}
         sq = os.path.join(ROOT, "profiles", "r01_sq_rollout.json")
