@@ -8,6 +8,7 @@
 #include "ses_cartpole.h"
 #include "ses_gru.h"
 #include "ses_gru_lockstep.h"
+#include "ses_gru_mfma.h"
 #include "ses_lander.h"
 #include "ses_internal.h"
 #include "ses_policy.h"
@@ -277,7 +278,7 @@ struct CartPoleLs {
     struct State {
         CartPoleState st;
     };
-    __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u)
+    __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u, int)
     {
         s.st = CartPoleState{u[0], u[1], u[2], u[3]};
     }
@@ -305,7 +306,7 @@ struct CartPoleLs64 {
     struct State {
         CartPoleState64 st;
     };
-    __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u)
+    __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u, int)
     {
         s.st = CartPoleState64{u[0], u[1], u[2], u[3]};
     }
@@ -332,10 +333,10 @@ struct LanderLs {
     struct State {
         LanderState st;
     };
-    __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u)
+    __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u, int slot)
     {
-        __shared__ float4 seg[4][GL_EB][LL_SEGMENTS];          // one terrain table per (wave, episode slot)
-        ll_reset(s.st, u, seg[threadIdx.x >> 6][threadIdx.x & 7]);
+        __shared__ float4 seg[4][GM_EB][LL_SEGMENTS];          // one terrain table per (wave, episode slot)
+        ll_reset(s.st, u, seg[threadIdx.x >> 6][slot]);
     }
     __device__ static __forceinline__ void observe(const State &s, float (&obs)[S]) { ll_obs(s.st, obs); }
     __device__ static __forceinline__ float step(State &s, const float (&logits)[A], const TanhEntry *tab, bool freeze,
@@ -360,7 +361,7 @@ __device__ __forceinline__ void gru_lockstep_batch(const TanhEntry *tanh_tab, Gr
     const int slot = lane & 7;
     const bool owner_valid = slot < nb;
     typename EnvT::State st;
-    EnvT::reset(st, init_rows + (size_t)(owner_valid ? slot : 0) * EnvT::INIT_W);   // padding slots replay episode 0
+    EnvT::reset(st, init_rows + (size_t)(owner_valid ? slot : 0) * EnvT::INIT_W, slot);   // padding slots replay episode 0
     float hreg[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) hreg[p] = 0.0f;                                  // GymEnvModel.reset()
@@ -437,6 +438,95 @@ __global__ __launch_bounds__(256) void k_rollout_gru_lockstep(const float *__res
             default: SES_LS_CASE(4, false); break;
         }
 #undef SES_LS_CASE
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA GRU rollout (ses_gru_mfma.h): one offspring per wave, up to 16 episodes are the columns of the
+// v_mfma_f32_16x16x4_f32 tiles; lane l simulates the env of episode (l & 15) (four identical replicas, so no lane
+// diverges).  Used for eval_ep_num >= 12.  launch_bounds(256, 2): 256 registers, two waves per SIMD.
+// SQ counters at E = 16 (tools/prof_mfma.sh): 106 MFMAs + ~600 VALU instructions per step; the matrix pipe is busy 56 %
+// of the kernel (MfmaUtil) and SQ_WAIT_INST_ANY is 54 % of the wave cycles: fp32 MFMA executes on the vector lanes
+// (its peak IS the vector peak), so the contraction and the VALU phases of the two resident waves take turns instead
+// of overlapping -- staggering the waves by a VALU phase changed nothing.
+template <typename EnvT, bool FIXED_LENGTH>
+__device__ __forceinline__ void gru_mfma_batch(const TanhEntry *tanh_tab, GruMfmaLds<EnvT::S, EnvT::A> &lds,
+                                               const GruMfma<EnvT::S, EnvT::A> &net, int lane, int nb,
+                                               const float *__restrict__ init_rows, int max_step, uint32_t obs_mask,
+                                               double *__restrict__ ret_out, int32_t *__restrict__ steps_out,
+                                               bool valid_row)
+{
+    constexpr int S = EnvT::S, A = EnvT::A;
+    const int slot = lane & 15;
+    const bool owner_valid = slot < nb;
+    typename EnvT::State st;
+    EnvT::reset(st, init_rows + (size_t)(owner_valid ? slot : 0) * EnvT::INIT_W, slot);   // padding columns replay episode 0
+    float hreg[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hreg[t][r] = 0.0f;                           // GymEnvModel.reset()
+    wave_lds_sync();
+    for (int i = lane; i < 32 * GM_EB; i += 64) (&lds.hT[0][0])[i] = 0.0f;
+    double ret = 0.0;
+    int steps = 0;
+    bool alive = true;
+    for (int t = 0; t < max_step; ++t) {
+        if constexpr (!FIXED_LENGTH) {
+            if (__ballot(alive & owner_valid) == 0ull) break;
+        }
+        float obs[S];
+        EnvT::observe(st, obs);
+        if (lane < GM_EB) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) lds.obsT[k][lane] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
+        }
+        wave_lds_sync();
+        net.step(tanh_tab, lds, hreg, lane);
+        const float4 lg4 = *reinterpret_cast<const float4 *>(&lds.logit[slot][0]);
+        const float all[4] = {lg4.x, lg4.y, lg4.z, lg4.w};
+        float logits[A];
+#pragma unroll
+        for (int o = 0; o < A; ++o) logits[o] = all[o];
+        bool term;
+        const bool freeze = FIXED_LENGTH ? false : !alive;
+        const float r = EnvT::step(st, logits, tanh_tab, freeze, term);
+        const int nsteps = steps + 1;
+        const bool finished = term | (nsteps >= max_step);
+        ret = alive ? ret + (double)r : ret;
+        steps = alive ? nsteps : steps;
+        alive = alive & !finished;
+    }
+    if (valid_row && lane < GM_EB && owner_valid) {
+        if (ret_out) ret_out[slot] = ret;
+        if (steps_out) steps_out[slot] = steps;
+    }
+}
+
+template <typename EnvT, bool FIXED_LENGTH>
+__global__ __launch_bounds__(256, 2) void k_rollout_gru_mfma(const float *__restrict__ theta,
+                                                          const float *__restrict__ init, int init_per_offspring,
+                                                          int n_rows, int E, int P, int max_step, uint32_t obs_mask,
+                                                          double *__restrict__ ep_return,
+                                                          int32_t *__restrict__ ep_steps)
+{
+    __shared__ TanhEntry tanh_tab[SES_TANH_N];
+    __shared__ __attribute__((aligned(16))) GruMfmaLds<EnvT::S, EnvT::A> ldsv[4];
+    stage_tanh_table(tanh_tab);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int row = blockIdx.x * 4 + wave;
+    const bool valid = row < n_rows;
+    row = valid ? row : n_rows - 1;
+    GruMfmaLds<EnvT::S, EnvT::A> &lds = ldsv[wave];
+    GruMfma<EnvT::S, EnvT::A> net;
+    net.load(theta + (size_t)row * P, lane, lds);
+    wave_lds_sync();
+    for (int e0 = 0; e0 < E; e0 += GM_EB) {
+        const int nb = E - e0 < GM_EB ? E - e0 : GM_EB;
+        const float *rows = init + ((size_t)(init_per_offspring ? row : 0) * E + e0) * EnvT::INIT_W;
+        double *ro = ep_return ? ep_return + (size_t)row * E + e0 : nullptr;
+        int32_t *so = ep_steps ? ep_steps + (size_t)row * E + e0 : nullptr;
+        gru_mfma_batch<EnvT, FIXED_LENGTH>(tanh_tab, lds, net, lane, nb, rows, max_step, obs_mask, ro, so, valid);
     }
 }
 
@@ -757,6 +847,18 @@ static void launch_rollout(const ses_handle *h, const float *theta, const float 
     else launch_rollout_b<LPE, 64>(h, theta, init, per, n_rows, mode, ep_return, ep_steps);
 }
 
+// eval_ep_num from which the GRU rollouts run on the matrix cores (development knob SES_GRU_MFMA_MIN_E).  Measured,
+// POMDP CartPole, 4096 offspring x 500 steps: the MFMA form takes 5.1 ms for any E <= 16 (the padded tile costs the
+// same), the VALU lockstep form 2.4 / 3.5 / 5.6 / 7.2 ms at E = 5 / 8 / 12 / 16 -- the crossover is at 12.
+static int gru_mfma_min_e()
+{
+    static const int v = [] {
+        const char *e = getenv("SES_GRU_MFMA_MIN_E");
+        return e ? atoi(e) : 12;
+    }();
+    return v;
+}
+
 static bool gru_sequential()
 {
     static const bool v = [] {  // development knob: SES_GRU_SEQUENTIAL=1 selects the episode-after-episode GRU kernels
@@ -824,7 +926,11 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
     }
     if (h->cfg.env_id == SES_ENV_LUNARLANDER) {
         SES_REQUIRE(mode == SES_MODE_EPISODIC, "ses_rollout: LunarLander has no fixed-length mode");
-        if (h->cfg.gru && !gru_sequential())
+        if (h->cfg.gru && !gru_sequential() && h->cfg.eval_ep_num >= gru_mfma_min_e())
+            hipLaunchKernelGGL((k_rollout_gru_mfma<LanderLs, false>), dim3(ceil_div(n_rows, 4)), dim3(256), 0,
+                               h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
+                               h->cfg.max_step, h->obs_mask, epr, ep_steps);
+        else if (h->cfg.gru && !gru_sequential())
             hipLaunchKernelGGL((k_rollout_gru_lockstep<LanderLs, false>), dim3(ceil_div(n_rows, 4)), dim3(256), 0,
                                h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
                                h->cfg.max_step, h->obs_mask, epr, ep_steps);
@@ -874,6 +980,16 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
                 hipLaunchKernelGGL((k_rollout_cartpole_mlp<4, false, 64, true>), dim3(blocks), dim3(64), 0, h->stream, theta,
                                    init, init_per_offspring, n_rows, E, h->P, T, h->obs_mask, epr, ep_steps);
         }
+    } else if (h->cfg.gru && !gru_sequential() && h->cfg.eval_ep_num >= gru_mfma_min_e()) {
+        const int blocks = ceil_div(n_rows, 4);
+        if (mode == SES_MODE_FIXED_LENGTH)
+            hipLaunchKernelGGL((k_rollout_gru_mfma<CartPoleLs, true>), dim3(blocks), dim3(256), 0, h->stream, theta,
+                               init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
+                               epr, ep_steps);
+        else
+            hipLaunchKernelGGL((k_rollout_gru_mfma<CartPoleLs, false>), dim3(blocks), dim3(256), 0, h->stream, theta,
+                               init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
+                               epr, ep_steps);
     } else if (h->cfg.gru && !gru_sequential()) {
         const int blocks = ceil_div(n_rows, 4);
         if (mode == SES_MODE_FIXED_LENGTH)

@@ -99,3 +99,50 @@ def test_gru_rollout_random_population_and_shards():
                             es.rollout(dev(theta[37:]), dev(init[37:])).cpu().numpy()])
     assert np.array_equal(bits(parts), bits(fit))
     es.close()
+
+
+@pytest.mark.parametrize("E", [12, 16, 20])
+def test_gru_rollout_on_the_matrix_cores_bit_exact(E):
+    """eval_ep_num >= 12 runs the GRU rollout with v_mfma_f32_16x16x4_f32 (ses_gru_mfma.h): episodes are the tile
+    columns (20 = one full batch of 16 + a batch of 4).  A run of MFMAs over ascending k-blocks is the fmaf chain
+    of the canonical arithmetic, so returns must still equal the C oracle's bit for bit, in both modes."""
+    from ses import HipES
+    rng = np.random.RandomState(E)
+    n = 70
+    theta = (rng.randn(n, 6562) * 0.4).astype(np.float32)
+    init = rng.uniform(-0.05, 0.05, (n, E, 4)).astype(np.float32)
+    for pomdp, mask in ((True, 0b1010), (False, 0)):
+        es = HipES("CartPole-v1", 4, 2, True, True, pomdp=pomdp, max_step=200, eval_ep_num=E)
+        o_fit, o_ret, o_steps = co.rollout_cartpole(theta, init, E, 200, gru=True, obs_mask=mask)
+        for mode in (0, 1):
+            fit, ep_ret, ep_steps = es.rollout(dev(theta), dev(init), mode=mode, want_episodes=True)
+            assert np.array_equal(ep_steps.cpu().numpy(), o_steps), (E, pomdp, mode)
+            assert np.array_equal(bits(fit.cpu().numpy()), bits(o_fit))
+        es.close()
+    assert o_steps.max() > 50                                   # some policies balance for a while
+
+
+def test_lander_gru_rollout_on_the_matrix_cores_bit_exact():
+    from ses import HipES
+    rng = np.random.RandomState(31)
+    n, E = 40, 13
+    theta = (rng.randn(n, 6756) * 0.3).astype(np.float32)
+    init = rng.uniform(0, 1, (n, E, 16)).astype(np.float32)
+    es = HipES("LunarLanderContinuous-v2", 8, 4, False, True, pomdp=True, max_step=120, eval_ep_num=E)
+    fit, ep_ret, ep_steps = es.rollout(dev(theta), dev(init), want_episodes=True)
+    o_fit, o_ret, o_steps = co.rollout_lander(theta, init, E, 120)
+    assert np.array_equal(ep_steps.cpu().numpy(), o_steps)
+    assert np.array_equal(ep_ret.cpu().numpy(), o_ret)
+    assert np.array_equal(bits(fit.cpu().numpy()), bits(o_fit))
+    es.close()
+
+
+def test_existing_gru_parity_tests_also_hold_on_the_mfma_path():
+    """The fixtures use 5 episodes (VALU lockstep path by default); rerun them with the MFMA path forced."""
+    import subprocess, sys
+    env = {**os.environ, "SES_GRU_MFMA_MIN_E": "1"}
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(here, "test_gpu_gru.py"),
+                          os.path.join(here, "test_gpu_lander.py"), "-k", "not mfma_path", "-m", "gpu"],
+                         capture_output=True, text=True, env=env, timeout=900, cwd=os.path.dirname(here))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
