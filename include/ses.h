@@ -130,7 +130,9 @@ int ses_policy_forward(ses_handle *h, const float *theta, const float *obs, floa
 /* ---- K3: SoA env step (envs/gym_wrapper.py:32-45 around the third-party gym physics) ------- */
 /* CartPole, one lane = one env, fp32 state in structure-of-arrays form.
  * status[i]: bits 0..30 steps taken, bit 31 done.  ret[i] += 1 per live step.
- * Algorithmic traffic 52 B / env-step: loads x,xd,th,thd,action,ret,status; stores all but action. */
+ * Algorithmic traffic 52 B / env-step: loads x,xd,th,thd,action,ret,status; stores all but action.
+ * States are saturated at |x|, |xd|, |thd| <= 1e4 and |th| <= 0.75 rad: past-terminal values only (an episode ends
+ * at |x| > 2.4 or |th| > 0.2095), which matter in SES_MODE_FIXED_LENGTH where finished envs keep stepping. */
 int ses_env_step(ses_handle *h, int32_t n, int32_t mode, float *x, float *xd, float *th, float *thd,
                  const int32_t *action, float *ret, uint32_t *status);
 
