@@ -157,18 +157,23 @@ __global__ __launch_bounds__(RANK_TILE / 2) void k_rank_tile_sort(const unsigned
     for (int e = threadIdx.x; e < RANK_TILE; e += RANK_TILE / 2) sorted[base + e] = t[e];   // ascending
 }
 
+// One workgroup = 256 offspring x one sorted tile: the tile (8 KB) is staged in LDS once and each thread binary-
+// searches it there (10 dependent LDS reads instead of 10 dependent L2 reads: 36 -> see DESIGN.md at 32 768).
 __global__ __launch_bounds__(256) void k_rank_search(const unsigned long long *__restrict__ keys,
                                                      const unsigned long long *__restrict__ sorted, int n,
                                                      int32_t *__restrict__ rank)
 {
+    __shared__ unsigned long long t[RANK_TILE];
+    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(sorted + (size_t)blockIdx.y * RANK_TILE);
+    for (int e = threadIdx.x; e < RANK_TILE / 2; e += 256) reinterpret_cast<ulonglong2 *>(t)[e] = src[e];
+    __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned long long ki = keys[i];
-    const unsigned long long *__restrict__ s = sorted + (size_t)blockIdx.y * RANK_TILE;   // one sorted tile
-    int lo = 0, hi = RANK_TILE;                      // first position with s[pos] > ki
+    int lo = 0, hi = RANK_TILE;                      // first position with t[pos] > ki
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (s[mid] > ki) hi = mid; else lo = mid + 1;
+        if (t[mid] > ki) hi = mid; else lo = mid + 1;
     }
     if (lo < RANK_TILE) atomicAdd(&rank[i], RANK_TILE - lo);
 }
