@@ -146,3 +146,21 @@ def test_existing_gru_parity_tests_also_hold_on_the_mfma_path():
                           os.path.join(here, "test_gpu_lander.py"), "-k", "not mfma_path", "-m", "gpu"],
                          capture_output=True, text=True, env=env, timeout=900, cwd=os.path.dirname(here))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("E", [1, 2, 3, 8, 9, 11])
+def test_gru_lockstep_episode_batches(E):
+    """The VALU lockstep kernel advances up to 8 episodes together: odd counts pad the last pair, 9 and 11 run a
+    second batch (8 + 1, 8 + 3).  All must equal the oracle bit for bit."""
+    from ses import HipES
+    rng = np.random.RandomState(100 + E)
+    n = 45
+    theta = (rng.randn(n, 6562) * 0.4).astype(np.float32)
+    init = rng.uniform(-0.05, 0.05, (n, E, 4)).astype(np.float32)
+    es = HipES("CartPole-v1", 4, 2, True, True, pomdp=True, max_step=150, eval_ep_num=E)
+    o_fit, _, o_steps = co.rollout_cartpole(theta, init, E, 150, gru=True, obs_mask=0b1010)
+    for mode in (0, 1):
+        fit, _, ep_steps = es.rollout(dev(theta), dev(init), mode=mode, want_episodes=True)
+        assert np.array_equal(ep_steps.cpu().numpy(), o_steps), (E, mode)
+        assert np.array_equal(bits(fit.cpu().numpy()), bits(o_fit))
+    es.close()
