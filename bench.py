@@ -184,6 +184,13 @@ def main():
             # this same workload, duration measured live above
             prof = json.load(open(sq))
             rate = prof["per_dispatch"]["SQ_INSTS_VALU"] / (roll_ms * 1e-3)
+            model = prof.get("issue_cycles_per_step")
+            if model:
+                # serial-issue estimate: SIMD cycles the loop bodies need if every instruction issued alone at its
+                # measured cadence, over the SIMD cycles the kernel had (1024 SIMDs x duration x measured clock)
+                need = sum(v["waves"] * v["cycles"] for k, v in model.items() if isinstance(v, dict)) * T
+                have = 1024 * roll_ms * 1e-3 * prof["clock_ghz_under_load"] * 1e9
+                result["rollout_kernel"]["valu_issue_model_frac"] = need / have
             result["rollout_kernel"].update({"valu_wave_instr_per_s": rate,
                                              "valu_issue_peak_per_s": prof["peak_valu_wave_instr_per_s"],
                                              "valu_issue_frac": rate / prof["peak_valu_wave_instr_per_s"],
