@@ -40,6 +40,8 @@ struct LanderState {
     float prev_shaping;
     int has_prev, sleep, leg0, leg1;
     const float4 *seg;       // LDS: this env's segment table [LL_SEGMENTS]
+    float o[6];              // observation components 0..5 of the current state (the step computes them for the
+                             // shaping reward; the policy reads the same values: five divisions saved per step)
     uint32_t key0, key1;
     int step;
 };
@@ -65,6 +67,15 @@ __device__ __forceinline__ void ll_terrain(float x, const float4 *seg, float &h,
 }
 
 __device__ __forceinline__ void ll_obs(const LanderState &s, float (&obs)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 6; ++k) obs[k] = s.o[k];
+    obs[6] = s.leg0 ? 1.0f : 0.0f;
+    obs[7] = s.leg1 ? 1.0f : 0.0f;
+}
+
+// the observation from the state variables (oracle/ses_oracle.c ll_obs)
+__device__ __forceinline__ void ll_obs_compute(const LanderState &s, float (&obs)[8])
 {
     obs[0] = (s.x - LL_W * 0.5f) / (LL_W * 0.5f);
     obs[1] = (s.y - (LL_HELIPAD_Y + 18.0f / LL_SCALE)) / (LL_H * 0.5f);
@@ -183,7 +194,9 @@ __device__ __forceinline__ float ll_step(LanderState &s, float a0, float a1, boo
     s.sleep = still ? s.sleep + 1 : 0;
 
     float obs[8];
-    ll_obs(s, obs);
+    ll_obs_compute(s, obs);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s.o[k] = obs[k];
     const float shaping = -100.0f * __builtin_sqrtf(fma_(obs[0], obs[0], obs[1] * obs[1])) -
                           100.0f * __builtin_sqrtf(fma_(obs[2], obs[2], obs[3] * obs[3])) -
                           100.0f * __builtin_fabsf(obs[4]) + 10.0f * obs[6] + 10.0f * obs[7];
