@@ -29,6 +29,15 @@ struct CartPoleState {
 
 SES_DEV float clamp_sym(float v, float lim) { return min_(max_(v, -lim), lim); }
 
+// the value c in a VGPR the optimiser cannot see through (device only)
+SES_DEV float register_constant(float c)
+{
+#if defined(__HIPCC__)
+    asm volatile("" : "+v"(c));
+#endif
+    return c;
+}
+
 // The step is split so that a fused kernel can overlap the action-independent half (sin/cos of the pole
 // angle, denominator) with the policy's LDS table reads; the arithmetic and its order are unchanged.
 struct CartPolePre {
@@ -71,7 +80,9 @@ SES_DEV CartPolePre cartpole_pre(const CartPoleState &s)
 }
 
 // advances s in place; returns true when the NEW state is terminal
-SES_DEV bool cartpole_post(CartPoleState &s, const CartPolePre &p, int action)
+// th_clamp: CP_TH_CLAMP; a fused loop passes it from a register it set up once (register_constant) so that the
+// clamp is a single v_med3_f32 -- with the literal the compiler emits v_max + v_min, one literal each
+SES_DEV bool cartpole_post(CartPoleState &s, const CartPolePre &p, int action, float th_clamp = CP_TH_CLAMP)
 {
     const float fom = action == 1 ? CP_FORCE_OVER_MASS : -CP_FORCE_OVER_MASS;
     // temp = (F + pml*thd^2*sin)/M ; thetaacc = (g*sin - cos*temp) / (l*(4/3 - mp*cos^2/M)) ;
@@ -82,7 +93,13 @@ SES_DEV bool cartpole_post(CartPoleState &s, const CartPolePre &p, int action)
     const float xacc = fma_(-CP_PML_OVER_MASS * thacc, p.cs, temp);
     const float nx = clamp_sym(fma_(CP_TAU, s.xd, s.x), CP_CLAMP);
     const float nxd = clamp_sym(fma_(CP_TAU, xacc, s.xd), CP_CLAMP);
-    const float nth = clamp_sym(fma_(CP_TAU, s.thd, s.th), CP_TH_CLAMP);
+#if defined(__HIPCC__)
+    // v_med3_f32(v, -lim, lim) == min(max(v, -lim), lim) for lim >= 0, NaN included (it returns the minimum of the
+    // non-NaN operands, as fmin / fmax do); the compiler makes this rewrite itself when lim is a literal
+    const float nth = __builtin_amdgcn_fmed3f(fma_(CP_TAU, s.thd, s.th), -th_clamp, th_clamp);
+#else
+    const float nth = clamp_sym(fma_(CP_TAU, s.thd, s.th), th_clamp);
+#endif
     const float nthd = clamp_sym(fma_(CP_TAU, thacc, s.thd), CP_CLAMP);
     s.x = nx; s.xd = nxd; s.th = nth; s.thd = nthd;
     return (nx < -CP_X_LIMIT) || (nx > CP_X_LIMIT) || (nth < -CP_THETA_LIMIT) || (nth > CP_THETA_LIMIT);
