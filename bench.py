@@ -41,6 +41,9 @@ def parse():
     # (clock ramp: 0.271 ms per generation at --steps 20 --warmup 3, 0.248 ms at these defaults, 0.251 ms at 2000/200)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--preroll", type=int, default=-1,
+                    help="untimed generations run before the warm-up so that the clocks have ramped whatever --warmup "
+                         "is (default: enough to make preroll + warmup = 300, about 75 ms); reported in config")
     ap.add_argument("--offspring-per-gpu", type=int, default=4096)
     ap.add_argument("--eval-ep-num", type=int, default=5)
     ap.add_argument("--max-step", type=int, default=500)
@@ -134,6 +137,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    preroll = args.preroll if args.preroll >= 0 else max(0, 300 - args.warmup)
+    for g in range(preroll):                                  # clock ramp; a generation is ~0.25 ms
+        generation(10 ** 7 + g)
+    mu.zero_(); m.zero_(); v.zero_()                           # the measured run starts from the same state as ever
+    state.update(sigma=sigma0, t=0)
     for g in range(args.warmup):
         generation(g)
     barrier()
@@ -158,6 +166,7 @@ def main():
                                 "CartPole-v1 openai_es MLP(4-32-2, P=226)") + ", fixed-length episodes, termination masked",
                    "offspring_per_gpu": n_local, "offspring_total": n_global, "eval_ep_num": E, "max_step": T,
                    "env_steps_per_generation": steps_per_gen, "noise": "rocRAND philox4x32_10",
+                   "preroll_generations": preroll,
                    "parallelism": f"population sharded over {world} GPU(s), fitness all-gather"},
     }
     if rank == 0:
