@@ -187,6 +187,14 @@ def main():
         result["rollout_kernel"] = {"ms": roll_ms, "perturb_ms": perturb_ms,
                                     "env_steps_per_s_one_gpu": n_local * E * T / (roll_ms * 1e-3),
                                     "bound": "valu-issue/latency (state and weights in VGPRs, no HBM traffic in the loop)"}
+        if args.gru and E >= int(os.environ.get("SES_GRU_MFMA_MIN_E", "12")):
+            # the GRU rollout runs on v_mfma_f32_16x16x4_f32 from 12 episodes up: 2 fc1 + 96 gate + 8 fc2 tiles per
+            # step and 16-episode batch, 2048 flop per tile instruction (padding columns included), fp32 MFMA peak
+            # 157.3 TFLOP/s (MI355X_MICROARCH.md, Matrix cores)
+            flops = 106 * 2048.0 * n_local * ((E + 15) // 16) * T
+            result["rollout_kernel"].update({"bound": "fp32 mfma + valu (serial)", "mfma_tflops": flops / (roll_ms * 1e-3) / 1e12,
+                                             "mfma_peak_tflops": 157.3,
+                                             "mfma_frac": flops / (roll_ms * 1e-3) / 157.3e12})
         sq = os.path.join(ROOT, "profiles", "r01_sq_rollout.json")
         if os.path.exists(sq) and not args.gru and n_local == 4096 and E == 5 and T == 500 and args.lanes_per_env == 0:
             # VALU issue roofline of the fused kernel: instruction count from the committed SQ counter profile of
