@@ -37,6 +37,7 @@ class ESLoop(BaseESLoop):
         self.seed_env = int((config or {}).get("env", {}).get("seed", 0)) if isinstance(config, dict) else 0
         self.shared_init = bool((config or {}).get("env", {}).get("shared_init", False)) if isinstance(config, dict) else False
         self.history = []
+        self._metrics = None
 
         stamp = datetime.now().strftime("%Y%m%d%H%M%S")
         self.save_dir = f"logs/{self.env.name}/{stamp}"
@@ -69,24 +70,26 @@ class ESLoop(BaseESLoop):
             start_time = time.time()
             ep_num += 1
 
-            rollout_start_time = time.time()
+            # rollout_t is the GPU time of the rollout phase (HIP events, no host wait); evaluate() ends with the one
+            # device read-back of a generation (best reward), so eval_t = everything else in the wall time
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
             results = self.rollout(offsprings)
-            torch.cuda.synchronize()
-            rollout_consumed_time = time.time() - rollout_start_time
-
-            eval_start_time = time.time()
+            ev1.record()
             offsprings, best_reward, curr_sigma = self.offspring_strategy.evaluate(results)
-            eval_consumed_time = time.time() - eval_start_time
-
+            ev1.synchronize()
             consumed_time = time.time() - start_time
+            rollout_consumed_time = ev0.elapsed_time(ev1) * 1e-3
+            eval_consumed_time = max(consumed_time - rollout_consumed_time, 0.0)
             self.history.append((best_reward, curr_sigma))
             self.ep5_rewards.append(best_reward)
             if rank0:                                   # wandb-free metrics: same quantities as loop.py:94-99
-                with open(self.save_dir + "/metrics.jsonl", "a") as f:
-                    f.write(json.dumps({"episode": ep_num, "best_reward": best_reward, "curr_sigma": curr_sigma,
-                                        "ep5_mean_reward": sum(self.ep5_rewards) / len(self.ep5_rewards),
-                                        "time": consumed_time, "rollout_t": rollout_consumed_time,
-                                        "eval_t": eval_consumed_time}) + "\n")
+                if self._metrics is None:
+                    self._metrics = open(self.save_dir + "/metrics.jsonl", "a", buffering=1)   # line-buffered
+                self._metrics.write(json.dumps({"episode": ep_num, "best_reward": best_reward, "curr_sigma": curr_sigma,
+                                                "ep5_mean_reward": sum(self.ep5_rewards) / len(self.ep5_rewards),
+                                                "time": consumed_time, "rollout_t": rollout_consumed_time,
+                                                "eval_t": eval_consumed_time}) + "\n")
             if rank0:
                 print(f"episode: {ep_num}, Best reward: {best_reward:.2f}, sigma: {curr_sigma:.3f}, "
                       f"time: {consumed_time:.2f}, rollout_t: {rollout_consumed_time:.2f}, "

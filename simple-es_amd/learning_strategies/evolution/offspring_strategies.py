@@ -89,7 +89,12 @@ class _DeviceStrategy(BaseOffspringStrategy):
         if self.noise == "numpy" and shard.world != 1:
             raise RuntimeError("noise='numpy' reproduces the reference's single global stream: run it on one process")
         lo, hi = shard.first, shard.first + shard.n_local
-        idx = torch.from_numpy(np.ascontiguousarray(parent_idx_host[lo:hi], dtype=np.int32)).to(self.dev.device)
+        local_idx = np.ascontiguousarray(parent_idx_host[lo:hi], dtype=np.int32)
+        cached = getattr(self, "_idx_cache", None)     # the parent map is the same every generation: upload it once
+        if cached is None or cached[0].shape != local_idx.shape or not np.array_equal(cached[0], local_idx):
+            cached = (local_idx.copy(), torch.from_numpy(local_idx).to(self.dev.device))
+            self._idx_cache = cached
+        idx = cached[1]
         self._last = {"parents": parents, "idx_host": np.asarray(parent_idx_host, dtype=np.int32), "sigma": sigma,
                       "gen": self.gen, "shard": shard}
         if shard.n_local == 0:                      # more ranks than offspring: this rank idles through the rollout
@@ -256,7 +261,7 @@ class openai_es(_DeviceStrategy):
     def evaluate(self, rewards):
         fit = self._fitness_tensor(rewards)
         _, weights = self.dev.rank_center(fit)
-        best_reward = float(fit.max().item())
+        best = fit.max()                          # read back at the very end: nothing below waits for the GPU
         a = self.optimizer.next_step_scale()
         opt = self.optimizer
         if self.noise == "philox":
@@ -267,6 +272,7 @@ class openai_es(_DeviceStrategy):
                                       self.mu_model, opt.m, opt.v)
         self.curr_sigma *= self.sigma_decay
         pop = self._gen_offsprings(self.agent_ids, self.mu_model, self.curr_sigma, self.offspring_num)
+        best_reward = float(best.item())          # the only synchronisation point of a generation
         return pop, best_reward, self.curr_sigma
 
     def get_wandb_cfg(self):

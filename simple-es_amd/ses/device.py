@@ -118,9 +118,13 @@ class HipES:
         self._chk(parent_idx, "parent_idx", torch.int32, (n_rows,), optional=True)
         self._chk(row_ids, "row_ids", torch.int32, (n_rows,), optional=True)
         if parent_idx is not None:
-            lo, hi = int(parent_idx.min()), int(parent_idx.max())
-            if hi >= K or lo < -K:
-                raise SesError(f"parent_idx outside [-{K}, {K})")
+            # the range check reads the tensor back (a device sync): once per (tensor, version, K), not per generation
+            key = (parent_idx.data_ptr(), parent_idx._version, parent_idx.numel(), K)
+            if getattr(self, "_idx_checked", None) != key:
+                lo, hi = int(parent_idx.min()), int(parent_idx.max())
+                if hi >= K or lo < -K:
+                    raise SesError(f"parent_idx outside [-{K}, {K})")
+                self._idx_checked = key
         theta = self.empty(n_rows, self.P) if out is None else self._chk(out, "theta", torch.float32, (n_rows, self.P))
         check(self._lib.ses_perturb(self._h, _ptr(parents), _ptr(parent_idx), _ptr(row_ids), float(sigma), int(seed),
                                     int(gen), int(first_row), int(n_rows), _ptr(theta)), "ses_perturb")
@@ -139,9 +143,13 @@ class HipES:
         self._chk(eps64, "eps64", torch.float64, (n_rows, self.P))
         self._chk(parent_idx, "parent_idx", torch.int32, (n_rows,), optional=True)
         if parent_idx is not None:
-            lo, hi = int(parent_idx.min()), int(parent_idx.max())
-            if hi >= K or lo < -K:
-                raise SesError(f"parent_idx outside [-{K}, {K})")
+            # the range check reads the tensor back (a device sync): once per (tensor, version, K), not per generation
+            key = (parent_idx.data_ptr(), parent_idx._version, parent_idx.numel(), K)
+            if getattr(self, "_idx_checked", None) != key:
+                lo, hi = int(parent_idx.min()), int(parent_idx.max())
+                if hi >= K or lo < -K:
+                    raise SesError(f"parent_idx outside [-{K}, {K})")
+                self._idx_checked = key
         theta = self.empty(n_rows, self.P)
         store = self.empty(n_rows, self.P) if want_eps_store else None
         check(self._lib.ses_perturb_host_noise(self._h, _ptr(parents), _ptr(parent_idx), _ptr(eps64), float(sigma),
