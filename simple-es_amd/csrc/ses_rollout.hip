@@ -223,19 +223,23 @@ __global__ __launch_bounds__(256) void k_rollout_cartpole_gru(const float *__res
                                                               const float *__restrict__ init, int init_per_offspring,
                                                               int n_rows, int E, int P, int max_step,
                                                               uint32_t obs_mask, double *__restrict__ ep_return,
-                                                              int32_t *__restrict__ ep_steps)
+                                                              int32_t *__restrict__ ep_steps, int ep_parallel)
 {
     __shared__ TanhEntry tanh_tab[SES_TANH_N];
     __shared__ __attribute__((aligned(16))) float vecs[4][64];
     stage_tanh_table(tanh_tab);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int row = blockIdx.x * 4 + wave;
-    const bool valid = row < n_rows;
-    row = valid ? row : n_rows - 1;
+    // ep_parallel: one wave per (offspring, episode) instead of one per offspring -- for populations too small to
+    // fill the chip the E episodes of an offspring run side by side and the rollout takes one episode's time
+    const int unit = blockIdx.x * 4 + wave, n_units = ep_parallel ? n_rows * E : n_rows;
+    const bool valid = unit < n_units;
+    const int u = valid ? unit : n_units - 1;
+    const int row = ep_parallel ? u / E : u;
+    const int ep_begin = ep_parallel ? u - row * E : 0, ep_end = ep_parallel ? ep_begin + 1 : E;
     GruSlice<4, 2> net;
     net.load(theta + (size_t)row * P, lane);
     float *vec = vecs[wave];
-    for (int ep = 0; ep < E; ++ep) {
+    for (int ep = ep_begin; ep < ep_end; ++ep) {
         const float *s0 = init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 4;
         CartPoleState st{s0[0], s0[1], s0[2], s0[3]};
         float h = 0.0f;                                   // GymEnvModel.reset(), neural_network.py:38-40
@@ -543,7 +547,8 @@ template <bool GRU>
 __global__ __launch_bounds__(256) void k_rollout_lander(const float *__restrict__ theta,
                                                         const float *__restrict__ init, int init_per_offspring,
                                                         int n_rows, int E, int P, int max_step, uint32_t obs_mask,
-                                                        double *__restrict__ ep_return, int32_t *__restrict__ ep_steps)
+                                                        double *__restrict__ ep_return, int32_t *__restrict__ ep_steps,
+                                                        int ep_parallel)
 {
     constexpr int S = 8, A = 4, LPE = 8;
     __shared__ TanhEntry tanh_tab[SES_TANH_N];
@@ -552,13 +557,15 @@ __global__ __launch_bounds__(256) void k_rollout_lander(const float *__restrict_
     stage_tanh_table(tanh_tab);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if constexpr (GRU) {
-        int row = blockIdx.x * 4 + wave;
-        const bool valid = row < n_rows;
-        row = valid ? row : n_rows - 1;
+        const int unit = blockIdx.x * 4 + wave, n_units = ep_parallel ? n_rows * E : n_rows;   // see k_rollout_cartpole_gru
+        const bool valid = unit < n_units;
+        const int u = valid ? unit : n_units - 1;
+        const int row = ep_parallel ? u / E : u;
+        const int ep_begin = ep_parallel ? u - row * E : 0, ep_end = ep_parallel ? ep_begin + 1 : E;
         GruSlice<S, A> net;
         net.load(theta + (size_t)row * P, lane);
         float *vec = vecs[wave];
-        for (int ep = 0; ep < E; ++ep) {
+        for (int ep = ep_begin; ep < ep_end; ++ep) {
             LanderState st;
             ll_reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 16, seg[wave]);
             float h = 0.0f;
@@ -864,6 +871,20 @@ static int gru_mfma_min_e()
     return v;
 }
 
+// Small populations: the chip is far from full and what a rollout costs is the latency of max_step sequential env
+// steps.  The lockstep kernel spends ~1.7 us per step (all E episodes of an offspring in one wave), the
+// episode-after-episode kernel ~0.75 us per step and episode -- launched with one wave per (offspring, episode) it
+// finishes in one episode's time.  Measured, POMDP CartPole, E = 5, 500 steps (lockstep / episode-parallel, ms):
+// 96 offspring 0.87 / 0.37, 400: 0.87 / 0.46, 800: 0.87 / 0.82, 1200: 1.22 / 1.13, 1600: 1.23 / 1.48, 4096: 2.41 / 3.50.
+static bool gru_episode_parallel(const ses_handle *h, long long episodes)
+{
+    static const int limit = [] {  // development knob: (offspring x episode) waves up to which the form is used
+        const char *e = getenv("SES_GRU_EP_PARALLEL_MAX");
+        return e ? atoi(e) : 4096;
+    }();
+    return episodes <= limit && h->cfg.eval_ep_num > 1;
+}
+
 static bool gru_sequential()
 {
     static const bool v = [] {  // development knob: SES_GRU_SEQUENTIAL=1 selects the episode-after-episode GRU kernels
@@ -931,7 +952,12 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
     }
     if (h->cfg.env_id == SES_ENV_LUNARLANDER) {
         SES_REQUIRE(mode == SES_MODE_EPISODIC, "ses_rollout: LunarLander has no fixed-length mode");
-        if (h->cfg.gru && !gru_sequential() && h->cfg.eval_ep_num >= gru_mfma_min_e())
+        const bool epp = h->cfg.gru && !gru_sequential() && gru_episode_parallel(h, (long long)episodes);
+        if (epp)
+            hipLaunchKernelGGL((k_rollout_lander<true>), dim3(ceil_div((long long)episodes, 4)), dim3(256), 0, h->stream,
+                               theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step,
+                               h->obs_mask, epr, ep_steps, 1);
+        else if (h->cfg.gru && !gru_sequential() && h->cfg.eval_ep_num >= gru_mfma_min_e())
             hipLaunchKernelGGL((k_rollout_gru_mfma<LanderLs, false>), dim3(ceil_div(n_rows, 4)), dim3(256), 0,
                                h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
                                h->cfg.max_step, h->obs_mask, epr, ep_steps);
@@ -942,11 +968,11 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
         else if (h->cfg.gru)
             hipLaunchKernelGGL((k_rollout_lander<true>), dim3(ceil_div(n_rows, 4)), dim3(256), 0, h->stream, theta, init,
                                init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, epr,
-                               ep_steps);
+                               ep_steps, 0);
         else
             hipLaunchKernelGGL((k_rollout_lander<false>), dim3(ceil_div((long long)episodes * 8, 256)), dim3(256), 0,
                                h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
-                               h->cfg.max_step, h->obs_mask, epr, ep_steps);
+                               h->cfg.max_step, h->obs_mask, epr, ep_steps, 0);
     } else if (h->cfg.env_id == SES_ENV_SIMPLE_SPREAD) {
         SES_REQUIRE(ep_steps == nullptr, "ses_rollout: simple_spread episodes have a fixed length, no ep_steps");
         const int blocks = ceil_div((long long)episodes * 8, 64);
@@ -985,6 +1011,16 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
                 hipLaunchKernelGGL((k_rollout_cartpole_mlp<4, false, 64, true>), dim3(blocks), dim3(64), 0, h->stream, theta,
                                    init, init_per_offspring, n_rows, E, h->P, T, h->obs_mask, epr, ep_steps);
         }
+    } else if (h->cfg.gru && !gru_sequential() && gru_episode_parallel(h, (long long)episodes)) {
+        const int blocks = ceil_div((long long)episodes, 4);
+        if (mode == SES_MODE_FIXED_LENGTH)
+            hipLaunchKernelGGL((k_rollout_cartpole_gru<true>), dim3(blocks), dim3(256), 0, h->stream, theta, init,
+                               init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
+                               epr, ep_steps, 1);
+        else
+            hipLaunchKernelGGL((k_rollout_cartpole_gru<false>), dim3(blocks), dim3(256), 0, h->stream, theta, init,
+                               init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
+                               epr, ep_steps, 1);
     } else if (h->cfg.gru && !gru_sequential() && h->cfg.eval_ep_num >= gru_mfma_min_e()) {
         const int blocks = ceil_div(n_rows, 4);
         if (mode == SES_MODE_FIXED_LENGTH)
@@ -1010,11 +1046,11 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
         if (mode == SES_MODE_FIXED_LENGTH)
             hipLaunchKernelGGL((k_rollout_cartpole_gru<true>), dim3(blocks), dim3(256), 0, h->stream, theta, init,
                                init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
-                               epr, ep_steps);
+                               epr, ep_steps, 0);
         else
             hipLaunchKernelGGL((k_rollout_cartpole_gru<false>), dim3(blocks), dim3(256), 0, h->stream, theta, init,
                                init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
-                               epr, ep_steps);
+                               epr, ep_steps, 0);
     } else {
         launch_cartpole_mlp(h, theta, init, init_per_offspring, n_rows, mode, epr, ep_steps);
     }

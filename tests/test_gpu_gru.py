@@ -108,7 +108,7 @@ def test_gru_rollout_on_the_matrix_cores_bit_exact(E):
     of the canonical arithmetic, so returns must still equal the C oracle's bit for bit, in both modes."""
     from ses import HipES
     rng = np.random.RandomState(E)
-    n = 70
+    n = 4200 // E + 1                                            # > 4096 episodes: past the episode-parallel small-population path
     theta = (rng.randn(n, 6562) * 0.4).astype(np.float32)
     init = rng.uniform(-0.05, 0.05, (n, E, 4)).astype(np.float32)
     for pomdp, mask in ((True, 0b1010), (False, 0)):
@@ -125,7 +125,7 @@ def test_gru_rollout_on_the_matrix_cores_bit_exact(E):
 def test_lander_gru_rollout_on_the_matrix_cores_bit_exact():
     from ses import HipES
     rng = np.random.RandomState(31)
-    n, E = 40, 13
+    n, E = 320, 13                                               # 4160 episodes: past the small-population path
     theta = (rng.randn(n, 6756) * 0.3).astype(np.float32)
     init = rng.uniform(0, 1, (n, E, 16)).astype(np.float32)
     es = HipES("LunarLanderContinuous-v2", 8, 4, False, True, pomdp=True, max_step=120, eval_ep_num=E)
@@ -137,14 +137,20 @@ def test_lander_gru_rollout_on_the_matrix_cores_bit_exact():
     es.close()
 
 
-def test_existing_gru_parity_tests_also_hold_on_the_mfma_path():
-    """The fixtures use 5 episodes (VALU lockstep path by default); rerun them with the MFMA path forced."""
+@pytest.mark.parametrize("knobs", [{"SES_GRU_EP_PARALLEL_MAX": "0"},
+                                   {"SES_GRU_EP_PARALLEL_MAX": "0", "SES_GRU_MFMA_MIN_E": "1"},
+                                   {"SES_GRU_EP_PARALLEL_MAX": "1000000"}],
+                         ids=["lockstep", "mfma", "episode_parallel"])
+def test_gru_parity_suites_on_every_kernel_path(knobs):
+    """ses_rollout picks the GRU kernel from the population size and episode count: one wave per (offspring, episode)
+    up to 4096 episodes, the VALU lockstep kernel above, the MFMA kernel from 12 episodes.  The fixtures and most
+    cases in these files are small, so rerun both GRU files with each path forced for every size."""
     import subprocess, sys
-    env = {**os.environ, "SES_GRU_MFMA_MIN_E": "1"}
+    env = {**os.environ, **knobs}
     here = os.path.dirname(os.path.abspath(__file__))
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(here, "test_gpu_gru.py"),
-                          os.path.join(here, "test_gpu_lander.py"), "-k", "not mfma_path", "-m", "gpu"],
-                         capture_output=True, text=True, env=env, timeout=900, cwd=os.path.dirname(here))
+                          os.path.join(here, "test_gpu_lander.py"), "-k", "not every_kernel_path", "-m", "gpu"],
+                         capture_output=True, text=True, env=env, timeout=1500, cwd=os.path.dirname(here))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
 
 
