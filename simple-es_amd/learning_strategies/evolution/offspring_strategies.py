@@ -120,10 +120,13 @@ class _DeviceStrategy(BaseOffspringStrategy):
         ids = np.asarray(ids_host, dtype=np.int32)
         if self.noise == "numpy":
             return self.dev.gather_rows(last["theta"], torch.from_numpy(ids).to(self.dev.device))
-        idx = torch.from_numpy(np.ascontiguousarray(last["idx_host"][ids])).to(self.dev.device)
-        rows = torch.from_numpy(ids).to(self.dev.device)
+        sel = np.ascontiguousarray(last["idx_host"][ids])
+        K = last["parents"].shape[0] if last["parents"].dim() == 2 else 1
+        if sel.size and (sel.max() >= K or sel.min() < -K):
+            raise ValueError("parent map out of range")
+        both = torch.from_numpy(np.stack([sel, ids])).to(self.dev.device)          # one upload for both index rows
         return self.dev.perturb(last["parents"], last["sigma"], self.seed, last["gen"], 0, len(ids),
-                                parent_idx=idx, row_ids=rows)
+                                parent_idx=both[0], row_ids=both[1], idx_in_range=True)
 
     def _fitness_tensor(self, rewards):
         if isinstance(rewards, torch.Tensor):

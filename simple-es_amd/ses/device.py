@@ -111,13 +111,16 @@ class HipES:
         check(self._lib.ses_sync(self._h), "ses_sync")
 
     # -- K1 -----------------------------------------------------------------------------------
-    def perturb(self, parents, sigma, seed, gen, first_row, n_rows, parent_idx=None, row_ids=None, out=None):
+    def perturb(self, parents, sigma, seed, gen, first_row, n_rows, parent_idx=None, row_ids=None, out=None,
+                idx_in_range=False):
+        """idx_in_range: the caller built parent_idx on the host and checked -K <= idx < K there (skips the device
+        read-back below)."""
         parents = parents.view(-1, self.P) if parents.dim() == 1 else parents
         K = parents.shape[0]
         self._chk(parents, "parents", torch.float32, (K, self.P))
         self._chk(parent_idx, "parent_idx", torch.int32, (n_rows,), optional=True)
         self._chk(row_ids, "row_ids", torch.int32, (n_rows,), optional=True)
-        if parent_idx is not None:
+        if parent_idx is not None and not idx_in_range:
             # the range check reads the tensor back (a device sync): once per (tensor, version, K), not per generation
             key = (parent_idx.data_ptr(), parent_idx._version, parent_idx.numel(), K)
             if getattr(self, "_idx_checked", None) != key:
