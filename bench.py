@@ -70,17 +70,21 @@ def env_step_roofline(es, n_env, launches=20):
     # `launches` back-to-back launches between two HIP events on the launch stream (torch's current stream
     # IS the handle's stream): the queue never drains, so the quotient is the kernel's own duration
     # (cross-checked against rocprofv3 --kernel-trace in profiles/).
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(launches):
-        es.env_step(*st, action, ret, status, mode=MODE_FIXED_LENGTH)
-    e1.record()
-    e1.synchronize()
-    avg = e0.elapsed_time(e1) * 1e-3 / launches
+    batches = []
+    for _ in range(7):                                         # median batch: a transient slow batch (~8 %) shows up
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # about once in ten
+        e0.record()
+        for _ in range(launches):
+            es.env_step(*st, action, ret, status, mode=MODE_FIXED_LENGTH)
+        e1.record()
+        e1.synchronize()
+        batches.append(e0.elapsed_time(e1) * 1e-3 / launches)
+    avg = sorted(batches)[len(batches) // 2]
     achieved = BYTES_PER_ENV_STEP * n_env / avg / 1e9
     return {"bound": "hbm", "kernel": "k_env_step_cartpole_v4", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "n_env": n_env, "avg_launch_us": avg * 1e6, "env_steps_per_s": n_env / avg,
+            "n_env": n_env, "avg_launch_us": avg * 1e6, "batch_avg_us": [round(b * 1e6, 2) for b in batches],
+            "env_steps_per_s": n_env / avg,
             "bytes_per_env_step": BYTES_PER_ENV_STEP}
 
 
