@@ -81,9 +81,25 @@ def env_step_roofline(es, n_env, launches=20):
         batches.append(e0.elapsed_time(e1) * 1e-3 / launches)
     avg = sorted(batches)[len(batches) // 2]
     achieved = BYTES_PER_ENV_STEP * n_env / avg / 1e9
+    # this box's streaming ceiling for the same byte count: a plain device-to-device copy (read half, write half)
+    half = BYTES_PER_ENV_STEP * n_env // 2
+    src, dst = torch.empty(half, dtype=torch.uint8, device="cuda"), torch.empty(half, dtype=torch.uint8, device="cuda")
+    dst.copy_(src)
+    copies = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        copies.append(e0.elapsed_time(e1) * 1e-3 / 10)
+    copy_gbs = 2 * half / sorted(copies)[len(copies) // 2] / 1e9
+    del src, dst
     return {"bound": "hbm", "kernel": "k_env_step_cartpole_v4", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "n_env": n_env, "avg_launch_us": avg * 1e6, "batch_avg_us": [round(b * 1e6, 2) for b in batches],
+            "copy_same_bytes_gbs": copy_gbs, "frac_of_copy": achieved / copy_gbs,
             "env_steps_per_s": n_env / avg,
             "bytes_per_env_step": BYTES_PER_ENV_STEP}
 
