@@ -174,6 +174,18 @@ int ses_es_update_stored(ses_handle *h, const double *weights, int32_t n, const 
 /* ---- K6: elite selection + mean (offspring_strategies.py:112-116, 234-248) ------------------ */
 /* elite_ids[j] = index of the offspring with rank j, j < k. */
 int ses_elite_ids(ses_handle *h, const int32_t *rank, int32_t n, int32_t k, int32_t *elite_ids);
+/* The elite bookkeeping of one generation in a single launch, nothing read back by the host:
+ *   elite_ids[j]        = index of the offspring with rank j (as ses_elite_ids);
+ *   elite_parent_idx[j] = parent_map[elite_ids[j]], the entry of the current population's parent map -- what
+ *                         ses_perturb(row_ids = elite_ids, parent_idx = elite_parent_idx) needs to rebuild the rows;
+ *   alias_first[j]      = the flags of ses_elite_mean for simple_evolution (offspring_strategies.py:234-248 sums the
+ *                         elites into elite 0 in place; while population slots 0 and 1 are the same module object,
+ *                         an elite in the other of the two slots doubles the running sum): set when *alias_state != 0,
+ *                         elite_ids[0] is 0 or 1, and elite_ids[j] is the other of 0 / 1;
+ *   *alias_state        is then updated: elite_ids[0] == 0, or elite_ids[0] == 1 while the state was set.
+ * alias_state and alias_first may be NULL together (simple_genetic).  k <= 1024. */
+int ses_elite_select(ses_handle *h, const int32_t *rank, int32_t n, int32_t k, const int32_t *parent_map,
+                     int32_t *alias_state, int32_t *elite_ids, int32_t *elite_parent_idx, int32_t *alias_first);
 /* rows[k,P] (the elites, best first) -> mean[P] = ((rows[0] + rows[1]) + ... ) / k in float32, the
  * reference's in-place order (:241-248).  alias_first[j] != 0 (j >= 1) marks an elite that is the same
  * module object as elite 0, for which the reference's `mu += elite` doubles the running sum

@@ -291,6 +291,33 @@ __global__ void k_elite_ids(const int32_t *__restrict__ rank, int n, int k, int3
     if (i < n && rank[i] < k) elite_ids[rank[i]] = i;
 }
 
+// one workgroup: the ids are needed together (the alias flags compare every elite with elite 0)
+__global__ __launch_bounds__(1024) void k_elite_select(const int32_t *__restrict__ rank, int n, int k,
+                                                       const int32_t *__restrict__ parent_map,
+                                                       int32_t *__restrict__ alias_state, int32_t *__restrict__ elite_ids,
+                                                       int32_t *__restrict__ elite_parent_idx,
+                                                       int32_t *__restrict__ alias_first)
+{
+    __shared__ int32_t ids[1024];
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const int r = rank[i];
+        if (r < k) ids[r] = i;
+    }
+    __syncthreads();
+    const int j = threadIdx.x;
+    const int first = ids[0];
+    const int state = alias_state ? *alias_state : 0;
+    if (j < k) {
+        const int id = ids[j];
+        elite_ids[j] = id;
+        elite_parent_idx[j] = parent_map[id];
+        if (alias_first)
+            alias_first[j] = (j > 0 && state != 0 && (first == 0 || first == 1) && (id == 0 || id == 1) && id != first) ? 1 : 0;
+    }
+    __syncthreads();                                            // every thread has read the old state
+    if (j == 0 && alias_state) *alias_state = (first == 0 || (first == 1 && state != 0)) ? 1 : 0;
+}
+
 __global__ void k_elite_mean(const float *__restrict__ rows, const int32_t *__restrict__ alias_first, int k, int P,
                              float *__restrict__ mean)
 {
@@ -449,6 +476,20 @@ int ses_elite_ids(ses_handle *h, const int32_t *rank, int32_t n, int32_t k, int3
     SES_REQUIRE(n >= 1 && k >= 1 && k <= n, "ses_elite_ids: need 1 <= k <= n");
     SES_HIP_TRY(hipSetDevice(h->cfg.device));
     hipLaunchKernelGGL(k_elite_ids, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, rank, n, k, elite_ids);
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+int ses_elite_select(ses_handle *h, const int32_t *rank, int32_t n, int32_t k, const int32_t *parent_map,
+                     int32_t *alias_state, int32_t *elite_ids, int32_t *elite_parent_idx, int32_t *alias_first)
+{
+    SES_REQUIRE(h && rank && parent_map && elite_ids && elite_parent_idx, "ses_elite_select: null argument");
+    SES_REQUIRE((alias_state == nullptr) == (alias_first == nullptr),
+                "ses_elite_select: alias_state and alias_first go together");
+    SES_REQUIRE(n >= 1 && k >= 1 && k <= n && k <= 1024, "ses_elite_select: need 1 <= k <= min(n, 1024)");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_elite_select, dim3(1), dim3(1024), 0, h->stream, rank, n, k, parent_map, alias_state, elite_ids,
+                       elite_parent_idx, alias_first);
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;
 }

@@ -70,6 +70,7 @@ class _DeviceStrategy(BaseOffspringStrategy):
         self.seed = int(seed)
         self.gen = 0                  # bumped by every _gen_offsprings: Philox generation key
         self.dev = None
+        self._elite_ids_dev = None
 
     # ---- plumbing -----------------------------------------------------------------------------
     def _bind(self, network, agent_ids):
@@ -128,6 +129,28 @@ class _DeviceStrategy(BaseOffspringStrategy):
         return self.dev.perturb(last["parents"], last["sigma"], self.seed, last["gen"], 0, len(ids),
                                 parent_idx=both[0], row_ids=both[1], idx_in_range=True)
 
+    def _select_elites(self, rank, k, alias_state=None):
+        """Elite ids, their rows and (simple_evolution) the aliasing flags without a host round trip: one
+        ses_elite_select launch on the rank vector and the device copy of the current parent map."""
+        last = self._last
+        cached = getattr(self, "_map_dev", None)
+        if cached is None or cached[0] is not last["idx_host"]:
+            cached = (last["idx_host"], torch.from_numpy(np.ascontiguousarray(last["idx_host"])).to(self.dev.device))
+            self._map_dev = cached
+        ids, sel, alias = self.dev.elite_select(rank, k, cached[1], alias_state)
+        self._elite_ids_dev = ids
+        if self.noise == "numpy":
+            rows = self.dev.gather_rows(last["theta"], ids)
+        else:
+            rows = self.dev.perturb(last["parents"], last["sigma"], self.seed, last["gen"], 0, k,
+                                    parent_idx=sel, row_ids=ids, idx_in_range=True)   # map checked at upload
+        return rows, alias
+
+    @property
+    def elite_ids(self):
+        """Global ids of the last elite selection (host copy on demand; the loop itself never reads them back)."""
+        return None if self._elite_ids_dev is None else self._elite_ids_dev.cpu().numpy()
+
     def _fitness_tensor(self, rewards):
         if isinstance(rewards, torch.Tensor):
             fit = rewards.to(device=self.dev.device, dtype=torch.float32).contiguous()
@@ -170,13 +193,12 @@ class simple_genetic(_DeviceStrategy):
     def evaluate(self, rewards):
         fit = self._fitness_tensor(rewards)
         rank, _ = self.dev.rank_center(fit)
-        best_reward = float(fit.max().item())
-        ids = self.dev.elite_ids(rank, self.elite_num).cpu().numpy()
-        self.elite_ids = ids
-        self.elite_models = self._rows(ids)
+        best = fit.max()
+        self.elite_models, _ = self._select_elites(rank, self.elite_num)
         pop = self._gen_offsprings(self.agent_ids, self.elite_models, self.elite_num, self.offspring_num,
                                    self.curr_sigma)
         self.curr_sigma *= self.sigma_decay       # decays AFTER regeneration (offspring_strategies.py:117-124)
+        best_reward = float(best.item())          # the only synchronisation point of a generation
         return pop, best_reward, self.curr_sigma
 
     def get_wandb_cfg(self):
@@ -190,7 +212,7 @@ class simple_evolution(_DeviceStrategy):
         self.elite_num = elite_num
         self.mu_model = None          # device float32[P]
         self.elite0 = None            # device float32[P]  (elite_models[0])
-        self._slots_alias = True      # population slots 0 and 1 are the same module object
+        self._alias_state = None      # device int32[1]: population slots 0 and 1 are the same module object
 
     def _population_size(self):
         return self.offspring_num + 1
@@ -208,29 +230,23 @@ class simple_evolution(_DeviceStrategy):
         self._bind(network, agent_ids)
         self.mu_model = self.dev.zeros(self.P)
         self.elite0 = self.dev.zeros(self.P)
-        self._slots_alias = True
+        self._alias_state = torch.ones(1, dtype=torch.int32, device=self.dev.device)
         return self._gen_offsprings(agent_ids, self.elite0, self.mu_model, self.curr_sigma, self.offspring_num)
 
     def evaluate(self, rewards):
         fit = self._fitness_tensor(rewards)
         rank, _ = self.dev.rank_center(fit)
-        best_reward = float(fit.max().item())
-        ids = self.dev.elite_ids(rank, self.elite_num).cpu().numpy()
-        self.elite_ids = ids
-        rows = self._rows(ids)
+        best = fit.max()
         # the reference sums the elites IN PLACE into elite[0]; an elite that is the same object as elite[0]
-        # (slots 0 and 1 while they alias) doubles the running sum instead of adding its own value
-        alias = np.zeros(self.elite_num, dtype=np.int32)
-        if self._slots_alias and ids[0] in (0, 1):
-            for j in range(1, self.elite_num):
-                if ids[j] in (0, 1) and ids[j] != ids[0]:
-                    alias[j] = 1
-        mean = self.dev.elite_mean(rows, torch.from_numpy(alias).to(self.dev.device) if alias.any() else None)
-        self._slots_alias = bool(ids[0] == 0 or (ids[0] == 1 and self._slots_alias))
+        # (slots 0 and 1 while they alias) doubles the running sum instead of adding its own value: the flags and
+        # the aliasing state are kept on the device by ses_elite_select (include/ses.h)
+        rows, alias = self._select_elites(rank, self.elite_num, self._alias_state)
+        mean = self.dev.elite_mean(rows, alias)
         self.mu_model = mean
         self.elite0 = mean                         # elite[0] was overwritten with the mean (aliasing quirk)
         self.curr_sigma *= self.sigma_decay
         pop = self._gen_offsprings(self.agent_ids, self.elite0, self.mu_model, self.curr_sigma, self.offspring_num)
+        best_reward = float(best.item())           # the only synchronisation point of a generation
         return pop, best_reward, self.curr_sigma
 
     def get_wandb_cfg(self):

@@ -63,6 +63,7 @@ SIGNATURES = {
     "ses_es_update_philox": [_vp, _vp, _i32, _i32, _u64, _u64, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
     "ses_es_update_stored": [_vp, _vp, _i32, _vp, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
     "ses_elite_ids": [_vp, _vp, _i32, _i32, _vp],
+    "ses_elite_select": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "ses_elite_mean": [_vp, _vp, _vp, _i32, _vp],
     "ses_gather_rows": [_vp, _vp, _vp, _i32, _vp],
 }

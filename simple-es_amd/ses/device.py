@@ -249,6 +249,21 @@ class HipES:
         check(self._lib.ses_elite_ids(self._h, _ptr(rank), int(n), int(k), _ptr(ids)), "ses_elite_ids")
         return ids
 
+    def elite_select(self, rank, k, parent_map, alias_state=None):
+        """One launch: (elite_ids[k], elite_parent_idx[k], alias_first[k] or None), all on the device.
+        alias_state: int32[1] device tensor updated in place (simple_evolution), or None (simple_genetic)."""
+        n = rank.shape[0]
+        self._chk(rank, "rank", torch.int32, (n,))
+        self._chk(parent_map, "parent_map", torch.int32, (n,))
+        self._chk(alias_state, "alias_state", torch.int32, (1,), optional=True)
+        if not 1 <= k <= min(n, 1024):
+            raise SesError(f"elite_select: need 1 <= k <= min(n, 1024), got k={k} n={n}")
+        out = self.empty(3, k, dtype=torch.int32)
+        alias = out[2] if alias_state is not None else None
+        check(self._lib.ses_elite_select(self._h, _ptr(rank), int(n), int(k), _ptr(parent_map), _ptr(alias_state),
+                                         _ptr(out[0]), _ptr(out[1]), _ptr(alias)), "ses_elite_select")
+        return out[0], out[1], alias
+
     def elite_mean(self, rows, alias_first=None):
         k = rows.shape[0]
         self._chk(rows, "rows", torch.float32, (k, self.P))

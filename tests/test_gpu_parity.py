@@ -427,6 +427,41 @@ def test_elite_selection_and_mean(es):
     assert_bit_equal(host(es.elite_mean(rows, dev(alias))), want, "elite mean with alias")
 
 
+@pytest.mark.parametrize("n,k", [(2, 1), (17, 5), (97, 10), (4097, 64), (65536, 1024)])
+def test_elite_select_matches_host_bookkeeping(es, n, k):
+    """ses_elite_select = elite ids + parent-map gather + the aliasing flags / state of simple_evolution
+    (offspring_strategies.py:234-248), checked against the host logic it replaces over a sequence of generations."""
+    rng = np.random.RandomState(n + k)
+    parent_map = rng.randint(-2, 3, n).astype(np.int32)
+    state_dev = dev(np.ones(1, np.int32))
+    state = True
+    for gen in range(6):
+        rank = rng.permutation(n).astype(np.int32)
+        if gen % 2 == 0 and n > 2:                       # make slots 0 and 1 elites often enough to exercise the flags
+            a, b = np.where(rank == 0)[0][0], np.where(rank == min(1, k - 1))[0][0]
+            rank[[0, a]] = rank[[a, 0]]
+            if k > 1:
+                b = np.where(rank == 1)[0][0]
+                rank[[1, b]] = rank[[b, 1]]
+        ids, sel, alias = es.elite_select(dev(rank), k, dev(parent_map), state_dev)
+        want_ids = np.empty(k, np.int32)
+        for i in range(n):
+            if rank[i] < k:
+                want_ids[rank[i]] = i
+        want_alias = np.zeros(k, np.int32)
+        if state and want_ids[0] in (0, 1):
+            for j in range(1, k):
+                if want_ids[j] in (0, 1) and want_ids[j] != want_ids[0]:
+                    want_alias[j] = 1
+        state = bool(want_ids[0] == 0 or (want_ids[0] == 1 and state))
+        assert np.array_equal(host(ids), want_ids)
+        assert np.array_equal(host(sel), parent_map[want_ids])
+        assert np.array_equal(host(alias), want_alias)
+        assert int(host(state_dev)[0]) == int(state)
+    ids2, sel2, alias2 = es.elite_select(dev(rank), k, dev(parent_map))       # simple_genetic form: no alias outputs
+    assert alias2 is None and np.array_equal(host(ids2), want_ids) and np.array_equal(host(sel2), parent_map[want_ids])
+
+
 def test_bad_arguments_raise_before_launch(es):
     from ses import SesError
     with pytest.raises(SesError):
