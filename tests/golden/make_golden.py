@@ -28,6 +28,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
+OUT = os.environ.get("SES_GOLDEN_OUT", HERE)      # another directory: regenerate without touching the committed files
 sys.path.insert(0, ROOT)
 sys.path.insert(0, REF)
 sys.modules["wandb"] = types.ModuleType("wandb")
@@ -108,7 +109,7 @@ def g1_forward():
     m = GymEnvModel(4, 2, True, False)
     m.zero_init()
     out["zero_init_action"] = np.array(m(np.ones((1, 4), dtype=np.float32)), dtype=np.int64)
-    np.savez_compressed(os.path.join(HERE, "g1_forward.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "g1_forward.npz"), **out)
     print("G1 written", {k: v.shape for k, v in out.items() if k.endswith("_theta")})
 
 
@@ -164,8 +165,8 @@ def g234_strategies():
     out["es_tied_rewards"] = np.array(tied)
     _, best, _ = strat.evaluate(tied)
     meta["es_tied"] = {"best": float(best)}
-    np.savez_compressed(os.path.join(HERE, "g234_strategies.npz"), **out)
-    with open(os.path.join(HERE, "g234_strategies.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, "g234_strategies.npz"), **out)
+    with open(os.path.join(OUT, "g234_strategies.json"), "w") as f:
         json.dump(meta, f, indent=1)
     print("G2-4 written", list(meta))
 
@@ -264,8 +265,8 @@ def g56_rollouts():
     meta["g5gru"] = {"N": int(theta_g.shape[0]), "mean_return": float(np.mean(rg))}
     print("G5-gru", meta["g5gru"])
 
-    np.savez_compressed(os.path.join(HERE, "g56_rollouts.npz"), **out)
-    with open(os.path.join(HERE, "g56_rollouts.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, "g56_rollouts.npz"), **out)
+    with open(os.path.join(OUT, "g56_rollouts.json"), "w") as f:
         json.dump(meta, f, indent=1)
 
 
@@ -295,8 +296,8 @@ def g7_spread():
         out[f"n{n_agents}_returns"] = np.array(rets, dtype=np.float64)
         meta[f"n{n_agents}"] = {"N": 48, "E": E, "P": int(P), "max_cycles": 25, "mean_return": float(np.mean(rets))}
         print("G7 spread", n_agents, meta[f"n{n_agents}"])
-    np.savez_compressed(os.path.join(HERE, "g7_spread.npz"), **out)
-    with open(os.path.join(HERE, "g7_spread.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, "g7_spread.npz"), **out)
+    with open(os.path.join(OUT, "g7_spread.json"), "w") as f:
         json.dump(meta, f, indent=1)
 
 
@@ -317,8 +318,8 @@ def g8_lander():
         load_flat(net, theta[i])
         env.rewind()
         rets.append(RolloutWorker((env, {"0": net}, E)))
-    np.savez_compressed(os.path.join(HERE, "g8_lander.npz"), theta=theta, init=init, returns=np.array(rets, dtype=np.float64))
-    with open(os.path.join(HERE, "g8_lander.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, "g8_lander.npz"), theta=theta, init=init, returns=np.array(rets, dtype=np.float64))
+    with open(os.path.join(OUT, "g8_lander.json"), "w") as f:
         json.dump({"N": 24, "E": E, "P": int(P), "max_step": 300, "mean_return": float(np.mean(rets)),
                    "min": float(np.min(rets)), "max": float(np.max(rets))}, f, indent=1)
     print("G8 lander", float(np.mean(rets)), float(np.min(rets)), float(np.max(rets)))

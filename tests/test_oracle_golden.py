@@ -205,3 +205,25 @@ def test_physics64_closes_most_of_the_gap_to_gym_float64(g56):
     agree64 = np.mean(np.abs(f64.astype(np.float64) - data["g5_returns_gym64"]) <= RETURN_TOL)
     agree32 = np.mean(np.abs(f32.astype(np.float64) - data["g5_returns_gym64"]) <= RETURN_TOL)
     assert agree64 >= 0.99 and agree64 > agree32
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree only exists in the build container")
+def test_committed_fixtures_are_what_the_generator_produces(tmp_path):
+    """tests/golden/make_golden.py (imports the reference) regenerates every committed fixture bit for bit."""
+    import subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "golden", "make_golden.py")], capture_output=True, text=True,
+                         env={**os.environ, "SES_GOLDEN_OUT": str(tmp_path)}, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = sorted(f for f in os.listdir(os.path.join(here, "golden")) if f.endswith((".npz", ".json")))
+    assert names and sorted(f for f in os.listdir(tmp_path) if f.endswith((".npz", ".json"))) == names
+    for f in names:
+        a, b = os.path.join(here, "golden", f), os.path.join(tmp_path, f)
+        if f.endswith(".json"):
+            assert json.load(open(a)) == json.load(open(b)), f
+        else:
+            x, y = np.load(a), np.load(b)
+            assert set(x.files) == set(y.files), f
+            for k in x.files:
+                assert x[k].dtype == y[k].dtype and x[k].shape == y[k].shape, (f, k)
+                assert x[k].tobytes() == y[k].tobytes(), (f, k)
