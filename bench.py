@@ -2,25 +2,43 @@
 """bench.py -- env-steps/sec of the simple-es population rollout + fitness loop on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
 
-Workload (BASELINE.json metric / configs[1]): CartPole-v1, openai_es, MLP policy (P = 226),
-4096 offspring PER GPU, eval_ep_num = 5, synthetic fixed-length episodes of 500 steps (termination
-masked: every counted env-step is a full policy forward + physics step).  One "step" = one
-generation of the hot path, everything on device:
-    Philox perturbation -> fused rollout kernel -> fitness all-gather (RCCL, N > 1) ->
-    rank-centring -> ES gradient + Adam.
-Inputs (mu, Adam moments, initial states) are resident in HBM before the timed region.
+N > 1 runs one rank per GPU.  Started without a launcher (WORLD_SIZE unset) the command spawns
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` as a CHILD process
+before anything touches a GPU, relays its output and returns its exit code; started by torch.distributed.run
+it is a rank.
 
-Extra legs (rank 0): `roofline` -- the standalone SoA env-step kernel at 2^24 envs against the HBM
-roof (SURVEY 8d: 52 algorithmic bytes per env-step), timed with HIP events on the launch stream;
-`cpu_baseline` -- the reference-structured Python multiprocessing port on the host cores (N=1 only).
+Workload (BASELINE.json metric / configs[1]): CartPole-v1, openai_es, MLP policy (P = 226), eval_ep_num = 5,
+synthetic fixed-length episodes of 500 steps (termination masked: every counted env-step is a full policy
+forward + physics step).  One "step" = one generation of the PRODUCT loop: `ESLoop.generation()` of
+simple-es_amd/learning_strategies/evolution/loop.py driven by the `openai_es` strategy object -- the same
+method `ESLoop.run()` (and therefore `run_es.py`) loops over, everything on device:
+    env resets (Philox) -> fused rollout kernel -> fitness all-gather (RCCL, N > 1) -> rank-centring ->
+    ES gradient + Adam -> Philox perturbation of the next population (member 0 = mu).
+Parameters, Adam moments and the population are resident in HBM before the timed region.
+
+Three population sizes are measured per run (`value` is the first):
+    weak      4096 offspring PER GPU   (per-GPU work fixed: "scaling": "weak")
+    strong    4096 offspring in total  (the literal reading of BASELINE.json's metric)
+    c4        65 536 offspring in total (BASELINE.json configs[3])
+each with the RCCL rank count, the all-gather time and the per-rank fitness-loop time.
+
+Extra legs (rank 0): `roofline` -- the standalone SoA env-step kernel at 2^24 envs against the HBM roof
+(SURVEY 8d: 52 algorithmic bytes per env-step), timed with HIP events on the launch stream;
+`loop_ms_per_generation` -- ESLoop.run() itself, prints and metrics included;
+`cpu_baseline` -- the reference-structured Python multiprocessing port on the host cores (N = 1 only).
 """
 import argparse
+import contextlib
+import hashlib
 import json
-import math
 import os
+import signal
+import socket
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -32,29 +50,64 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured achievable
 BYTES_PER_ENV_STEP = 52        # 7 dword loads + 6 dword stores
+METRIC = "env-steps/sec (whole node), CartPole openai_es pop=4096 at 1/2/4/8 GPUs"
+PARITY_NOTE = ("rollout returns bit-exact vs the C oracle; within 1e-4 of the reference RolloutWorker driven over the "
+               "build's own fp32 CartPole (fixture G5); vs a gym-faithful float64 CartPole the same return for 95 % of "
+               "the G5 policies (99.2 % with env.physics: float64) -- gym itself is not pinned by the reference")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # 50 + 500 generations = 0.14 s of GPU time: the first few dozen generations after an idle period run ~8 % slower
-    # (clock ramp: 0.271 ms per generation at --steps 20 --warmup 3, 0.248 ms at these defaults, 0.251 ms at 2000/200)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--blocks", type=int, default=25,
+                    help="the --steps generation block is timed this many times; ms_per_step is the median block")
     ap.add_argument("--preroll", type=int, default=-1,
                     help="untimed generations run before the warm-up so that the clocks have ramped whatever --warmup "
                          "is (default: enough to make preroll + warmup = 300, about 75 ms); reported in config")
     ap.add_argument("--offspring-per-gpu", type=int, default=4096)
     ap.add_argument("--eval-ep-num", type=int, default=5)
     ap.add_argument("--max-step", type=int, default=500)
-    ap.add_argument("--lanes-per-env", type=int, default=0)
     ap.add_argument("--roofline-envs", type=int, default=1 << 24)
+    ap.add_argument("--loop-generations", type=int, default=1000, help="generations of the ESLoop.run() leg")
     ap.add_argument("--gru", action="store_true", help="GRU policy on POMDP CartPole instead of the headline MLP workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the strong / c4 / loop legs")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="ranks only rendezvous and all-gather their rank ids (spawn-path check, needs no GPU)")
+    ap.add_argument("--spawn-timeout", type=float, default=3000.0)
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# parent: spawn one rank per GPU (no HIP call in this process)
+def spawn(args):
+    backend = os.environ.get("SES_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and not args.rendezvous_only:
+        n_dev = torch.cuda.device_count()                      # counts devices without creating a HIP context
+        if n_dev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this machine shows {n_dev}",
+                  file=sys.stderr)
+            return 3
+    with socket.socket() as s:                                 # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this host
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=args.spawn_timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)                    # exactly the process group started above
+        print(f"bench.py: ranks did not finish within {args.spawn_timeout:.0f} s", file=sys.stderr)
+        return 124
+
+
+# ---------------------------------------------------------------------------------------------------------------
 def env_step_roofline(es, n_env, launches=20):
     """Average duration of k_env_step_cartpole over `launches` launches, HIP events on the launch stream."""
     from ses import MODE_FIXED_LENGTH
@@ -104,145 +157,296 @@ def env_step_roofline(es, n_env, launches=20):
             "bytes_per_env_step": BYTES_PER_ENV_STEP}
 
 
-def main():
-    args = parse()
+def kernel_code_hash(symbol_prefix):
+    """sha256 of the gfx950 machine code of the kernels whose mangled name contains `symbol_prefix`, taken from the
+    library that is loaded (tools/kernel_hash.py).  None when the binutils are not available."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import kernel_hash
+        from ses import _lib
+        return kernel_hash.hash_kernels(_lib.LIB_PATH, symbol_prefix)
+    except Exception:
+        return None
+
+
+def attach_traffic(roofline, n_env):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+    tools/collect_pmc.py) -- attached only when the committed file was collected on THIS machine code."""
+    newest = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+        if name.endswith("_pmc_env_step.json"):
+            newest = os.path.join(ROOT, "profiles", name)
+    if newest is None or n_env != (1 << 24):
+        return
+    pmc = json.load(open(newest))
+    now = kernel_code_hash("k_env_step_cartpole_v4")
+    roofline["kernel_code_sha256"] = now
+    if pmc.get("kernel_code_sha256") and now and pmc["kernel_code_sha256"] == now:
+        roofline["traffic"] = pmc["traffic_bytes_per_launch"]
+        roofline["traffic_source"] = os.path.relpath(newest, ROOT)
+    else:
+        roofline["traffic_note"] = (f"{os.path.relpath(newest, ROOT)} was collected on different machine code of this "
+                                    "kernel (or carries no hash): not attached")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class Job:
+    """One population size driven through the product loop (builder.build_loop -> ESLoop + openai_es)."""
+
+    def __init__(self, args, n_global, world):
+        import builder
+        self.n_global, self.world = n_global, world
+        self.E, self.T = args.eval_ep_num, args.max_step
+        cfg = {"env": {"name": "CartPole-v1", "max_step": self.T, "pomdp": bool(args.gru), "seed": 0,
+                       "shared_init": True, "fixed_length": True},
+               "network": {"name": "gym_model", "num_state": 4, "num_action": 2, "discrete_action": True,
+                           "gru": bool(args.gru)},
+               "strategy": {"name": "openai_es", "init_sigma": 0.1, "sigma_decay": 0.999, "learning_rate": 0.05,
+                            "offspring_num": n_global, "seed": 0}}
+        self.cfg = cfg
+        self.loop = builder.build_loop(cfg, 0, 1, self.E, False, 10 ** 9)
+        self.pop = None
+
+    def reset(self):
+        strat = self.loop.offspring_strategy
+        strat.curr_sigma = strat.init_sigma
+        self.pop = strat.init_offspring(self.loop.network, self.loop.env.get_agent_ids())
+
+    def generations(self, k):
+        loop, pop = self.loop, self.pop
+        for _ in range(k):
+            pop, _best, _sigma, _ev = loop.generation(pop)
+        self.pop = pop
+
+    def steps_per_generation(self):
+        return self.n_global * self.E * self.T
+
+    def phases(self, reps=21):
+        """Median GPU time (us, HIP events on the launch stream) of the three phases of a generation on this rank."""
+        loop, strat = self.loop, self.loop.offspring_strategy
+        rows = []
+        for _ in range(reps):
+            pop = self.pop
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            shard = pop.shard
+            ev[0].record()
+            init = loop.dev.init_states_uniform(loop.seed_env, pop.gen, 0, 1, shared=True)[0]
+            local = loop.dev.rollout(pop.theta, init, mode=loop.mode)
+            ev[1].record()
+            fit = shard.allgather_fitness(local, dev=loop.dev)
+            ev[2].record()
+            self.pop, _b, _s = strat.evaluate_async(fit)
+            ev[3].record()
+            ev[3].synchronize()
+            rows.append([ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(3)])
+        med = [statistics.median(r[i] for r in rows) for i in range(3)]
+        return {"rollout_us": med[0], "allgather_us": med[1], "fitness_loop_us": med[2]}
+
+
+def timed_blocks(job, steps, blocks, barrier, dist, world):
+    """`blocks` times: EXACTLY `steps` generations between barrier + synchronize on both sides, MAX over ranks."""
+    out = []
+    for _ in range(blocks):
+        barrier()
+        t0 = time.perf_counter()
+        job.generations(steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        out.append(dt)
+    return out
+
+
+def summarise(job, steps, times):
+    per = sorted(t / steps for t in times)
+    med = statistics.median(per)
+    return {"offspring_total": job.n_global, "offspring_per_gpu": -(-job.n_global // job.world),
+            "value": job.steps_per_generation() / med, "unit": "env-steps/s", "ms_per_step": med * 1e3,
+            "ms_per_step_min": per[0] * 1e3, "ms_per_step_max": per[-1] * 1e3, "blocks": len(per), "steps": steps}
+
+
+def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    args.gpus = world
+    backend = os.environ.get("SES_BENCH_BACKEND", "nccl")      # "gloo": test rigs where ranks share one GPU
     dist = None
+    if args.rendezvous_only:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        got = [None] * world
+        dist.all_gather_object(got, rank)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "world": world, "ranks": got}))
+        dist.destroy_process_group()
+        return 0
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1 or (backend == "nccl" and n_dev < world):
+        print(f"bench.py: rank {rank} sees {n_dev} GPU(s), {world} needed", file=sys.stderr)
+        return 3
+    local_rank = local_rank % n_dev
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("SES_BENCH_BACKEND", "nccl")      # "gloo": test rigs where ranks share one GPU
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-
-    from ses import HipES, MODE_FIXED_LENGTH
-    from ses.parallel import Shard
-
-    n_local, E, T = args.offspring_per_gpu, args.eval_ep_num, args.max_step
-    n_global = n_local * world
-    first = rank * n_local
-    es = HipES("CartPole-v1", 4, 2, True, args.gru, pomdp=args.gru, max_step=T, eval_ep_num=E, device=local_rank,
-               lanes_per_env=args.lanes_per_env)
-    lr, sigma0, decay, seed = 0.05, 0.1, 0.999, 0
-    mu, m, v = es.zeros(es.P), es.zeros(es.P), es.zeros(es.P)
-    init = es.init_states_uniform(seed, 0, 0, 1, shared=True)[0].contiguous()      # [E,4], common random numbers
-    theta = es.empty(n_local, es.P)
-    fit_local = es.empty(n_local)
-    shard = Shard(n_global)                                   # rank r owns rows [r*n_local, (r+1)*n_local)
-    assert (shard.first, shard.n_local) == (first, n_local)
-    state = {"sigma": sigma0, "t": 0}
-
-    def generation(gen):
-        es.perturb(mu, state["sigma"], seed, gen, first, n_local, out=theta)        # row 0 of a real run is mu itself
-        es.rollout(theta, init, mode=MODE_FIXED_LENGTH, fitness=fit_local)
-        fit_all = shard.allgather_fitness(fit_local)          # RCCL all-gather of N*4 bytes (no-op at world 1)
-        _, w = es.rank_center(fit_all)
-        state["t"] += 1
-        t = state["t"]
-        a = lr * math.sqrt(1 - 0.999 ** t) / (1 - 0.99 ** t)
-        es.es_update_philox(w, seed, gen, lr, state["sigma"], a, mu, m, v, skip_row0=False)
-        state["sigma"] *= decay
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    E, T = args.eval_ep_num, args.max_step
+    work = tempfile.mkdtemp(prefix="ses_bench_")               # ESLoop writes logs/<env>/<stamp>/ under the cwd
+    os.chdir(work)
     preroll = args.preroll if args.preroll >= 0 else max(0, 300 - args.warmup)
-    for g in range(preroll):                                  # clock ramp; a generation is ~0.25 ms
-        generation(10 ** 7 + g)
-    mu.zero_(); m.zero_(); v.zero_()                           # the measured run starts from the same state as ever
-    state.update(sigma=sigma0, t=0)
-    for g in range(args.warmup):
-        generation(g)
-    barrier()
-    t0 = time.perf_counter()
-    for g in range(args.warmup, args.warmup + args.steps):
-        generation(g)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
 
-    steps_per_gen = n_global * E * T
-    value = steps_per_gen * args.steps / dt
+    # ---- headline: weak scaling, 4096 offspring per GPU ---------------------------------------------------------
+    job = Job(args, args.offspring_per_gpu * world, world)
+    job.reset()
+    job.generations(preroll)                                   # clock ramp; a generation is ~0.25 ms
+    job.reset()                                                # the measured run starts from the zero network
+    job.generations(args.warmup)
+    times = timed_blocks(job, args.steps, max(args.blocks, 1), barrier, dist, world)
+    weak = summarise(job, args.steps, times)
+    comm_rank, comm_world, rccl_version = job.loop.dev.comm_info()
+    weak.update(job.phases())
+    weak["rccl_ranks"] = comm_world
+
     result = {
-        "metric": "env-steps/sec (whole node), CartPole openai_es pop=4096 at 1/2/4/8 GPUs",
-        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "metric": METRIC, "value": weak["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": weak["ms_per_step"], "ms_per_step_min": weak["ms_per_step_min"],
+        "ms_per_step_max": weak["ms_per_step_max"], "blocks": weak["blocks"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("POMDP CartPole-v1 openai_es GRU(4-32-GRU32-2, P=6562)" if args.gru else
                                 "CartPole-v1 openai_es MLP(4-32-2, P=226)") + ", fixed-length episodes, termination masked",
-                   "offspring_per_gpu": n_local, "offspring_total": n_global, "eval_ep_num": E, "max_step": T,
-                   "env_steps_per_generation": steps_per_gen, "noise": "rocRAND philox4x32_10",
-                   "preroll_generations": preroll,
-                   "parallelism": f"population sharded over {world} GPU(s), fitness all-gather"},
+                   "timed_call": "ESLoop.generation() x steps (the product loop's own method), openai_es strategy object",
+                   "offspring_per_gpu": args.offspring_per_gpu, "offspring_total": job.n_global, "eval_ep_num": E,
+                   "max_step": T, "env_steps_per_generation": job.steps_per_generation(),
+                   "noise": "rocRAND philox4x32_10", "preroll_generations": preroll,
+                   "parallelism": f"population sharded over {world} GPU(s), fitness all-gather "
+                                  f"(ses_allgather_fitness, RCCL {rccl_version}, {comm_world} rank(s))" if comm_world else
+                                  f"population on {world} GPU(s)" + ("" if world == 1 else f", fitness all-gather via torch.distributed/{backend}")},
+        "parity": PARITY_NOTE,
+        "weak_4096_per_gpu": weak,
     }
+
+    # ---- the two other readings of the metric ------------------------------------------------------------------------
+    if not args.no_extras:
+        x_steps, x_blocks = min(args.steps, 100), 7
+        for key, n_total in (("strong_4096_total", 4096), ("c4_65536_total", 65536)):
+            if key == "strong_4096_total" and world == 1 and args.offspring_per_gpu == 4096:
+                result[key] = dict(weak, note="same job as weak_4096_per_gpu at 1 GPU")
+                continue
+            try:
+                j = Job(args, n_total, world)
+                j.reset()
+                j.generations(30)
+                t = timed_blocks(j, x_steps, x_blocks, barrier, dist, world)
+                rec = summarise(j, x_steps, t)
+                rec.update(j.phases())
+                rec["rccl_ranks"] = j.loop.dev.comm_info()[1]
+                result[key] = rec
+                del j
+            except Exception as exc:                                 # the headline line must still be printed
+                result[key] = {"error": repr(exc)}
+
+        # ---- the loop a user runs: ESLoop.run() with its prints and metrics.jsonl ------------------------------------
+        try:
+            import builder
+            gens = args.loop_generations if args.steps >= 100 else min(args.loop_generations, 300)
+            loop = builder.build_loop(job.cfg, gens, 1, E, False, 10 ** 9)
+            barrier()
+            t0 = time.perf_counter()
+            with open(os.devnull, "w") as sink, contextlib.redirect_stdout(sink):
+                loop.run()
+            barrier()
+            result["loop_ms_per_generation"] = (time.perf_counter() - t0) / gens * 1e3
+            result["loop_generations"] = gens
+            result["loop_vs_step"] = result["loop_ms_per_generation"] / result["ms_per_step"]
+            del loop
+        except Exception as exc:
+            result["loop_error"] = repr(exc)
+
+    es = job.loop.dev
     if rank == 0:
         # per-kernel view of one generation (rank 0, HIP events on the launch stream)
+        pop = job.pop
+        init = es.init_states_uniform(0, 0, 0, 1, shared=True)[0]
         samples = []
         torch.cuda.synchronize()
-        for rep in range(9):                                   # median of 9 back-to-back generations' kernels
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        for rep in range(9):                                   # median of 9 rollout launches
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             ev[0].record()
-            es.perturb(mu, state["sigma"], seed, 10 ** 6 + rep, first, n_local, out=theta)
+            es.rollout(pop.theta, init, mode=job.loop.mode)
             ev[1].record()
-            es.rollout(theta, init, mode=MODE_FIXED_LENGTH, fitness=fit_local)
-            ev[2].record()
-            ev[2].synchronize()
-            samples.append((ev[1].elapsed_time(ev[2]), ev[0].elapsed_time(ev[1])))
-        samples.sort()
-        roll_ms, perturb_ms = samples[len(samples) // 2]
-        result["rollout_kernel"] = {"ms": roll_ms, "perturb_ms": perturb_ms,
-                                    "env_steps_per_s_one_gpu": n_local * E * T / (roll_ms * 1e-3),
-                                    "bound": "valu-issue/latency (state and weights in VGPRs, no HBM traffic in the loop)"}
-        if args.gru and E >= int(os.environ.get("SES_GRU_MFMA_MIN_E", "12")):
+            ev[1].synchronize()
+            samples.append(ev[0].elapsed_time(ev[1]))
+        roll_ms = statistics.median(samples)
+        n_local = pop.theta.shape[0]
+        result["rollout_kernel"] = {"ms": roll_ms, "env_steps_per_s_one_gpu": n_local * E * T / (roll_ms * 1e-3),
+                                    "bound": "valu-issue/latency (state and weights in VGPRs, no HBM traffic in the loop)",
+                                    "mfma": "not used at eval_ep_num < 12: fp32 MFMA runs at the VALU rate and a 16-column "
+                                            "tile would be 5/16 full (profiles/r01_mfma_vs_valu_gru.txt)"}
+        if args.gru and E >= 12:
             # the GRU rollout runs on v_mfma_f32_16x16x4_f32 from 12 episodes up: 2 fc1 + 96 gate + 8 fc2 tiles per
             # step and 16-episode batch, 2048 flop per tile instruction (padding columns included), fp32 MFMA peak
             # 157.3 TFLOP/s (MI355X_MICROARCH.md, Matrix cores)
             flops = 106 * 2048.0 * n_local * ((E + 15) // 16) * T
             result["rollout_kernel"].update({"bound": "fp32 mfma + valu (serial)", "mfma_tflops": flops / (roll_ms * 1e-3) / 1e12,
                                              "mfma_peak_tflops": 157.3,
-                                             "mfma_frac": flops / (roll_ms * 1e-3) / 157.3e12})
-        sq = os.path.join(ROOT, "profiles", "r01_sq_rollout.json")
-        if os.path.exists(sq) and not args.gru and n_local == 4096 and E == 5 and T == 500 and args.lanes_per_env == 0:
+                                             "mfma_frac": flops / (roll_ms * 1e-3) / 157.3e12,
+                                             "mfma": "v_mfma_f32_16x16x4_f32; MfmaUtil 56 % in profiles/r01_sq_gru_mfma.txt"})
+        sq = None
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+            if name.endswith("_sq_rollout.json"):
+                sq = os.path.join(ROOT, "profiles", name)
+        if sq and not args.gru and n_local == 4096 and E == 5 and T == 500:
             # VALU issue roofline of the fused kernel: instruction count from the committed SQ counter profile of
-            # this same workload, duration measured live above
+            # this same workload (attached only while the kernel's machine code is the profiled one), duration live
             prof = json.load(open(sq))
-            rate = prof["per_dispatch"]["SQ_INSTS_VALU"] / (roll_ms * 1e-3)
-            model = prof.get("issue_cycles_per_step")
-            if model:
-                # serial-issue estimate: SIMD cycles the loop bodies need if every instruction issued alone at its
-                # measured cadence, over the SIMD cycles the kernel had (1024 SIMDs x duration x measured clock)
-                need = sum(v["waves"] * v["cycles"] for k, v in model.items() if isinstance(v, dict)) * T
-                have = 1024 * roll_ms * 1e-3 * prof["clock_ghz_under_load"] * 1e9
-                result["rollout_kernel"]["valu_issue_model_frac"] = need / have
-            result["rollout_kernel"].update({"valu_wave_instr_per_s": rate,
-                                             "valu_issue_peak_per_s": prof["peak_valu_wave_instr_per_s"],
-                                             "valu_issue_frac": rate / prof["peak_valu_wave_instr_per_s"],
-                                             "valu_source": "profiles/r01_sq_rollout.json"})
+            now = kernel_code_hash("k_rollout_cartpole_mlp")
+            result["rollout_kernel"]["kernel_code_sha256"] = now
+            if not prof.get("kernel_code_sha256") or prof["kernel_code_sha256"] == now:
+                rate = prof["per_dispatch"]["SQ_INSTS_VALU"] / (roll_ms * 1e-3)
+                result["rollout_kernel"].update({"valu_wave_instr_per_s": rate,
+                                                 "valu_issue_peak_per_s": prof["peak_valu_wave_instr_per_s"],
+                                                 "valu_issue_frac": rate / prof["peak_valu_wave_instr_per_s"],
+                                                 "valu_source": os.path.relpath(sq, ROOT)})
         if not args.no_roofline:
-          try:
-            result["roofline"] = env_step_roofline(es, args.roofline_envs)
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_env_step.json")
-            if os.path.exists(pmc) and args.roofline_envs == (1 << 24):
-                # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-                # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/prof_pmc.sh); not collectable in-process
-                result["roofline"]["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch"]
-                result["roofline"]["traffic_source"] = "profiles/r01_pmc_env_step.json"
-          except Exception as exc:                                   # the headline line must still be printed
-            result["roofline_error"] = repr(exc)
+            try:
+                result["roofline"] = env_step_roofline(es, args.roofline_envs)
+                attach_traffic(result["roofline"], args.roofline_envs)
+            except Exception as exc:                                   # the headline line must still be printed
+                result["roofline_error"] = repr(exc)
+        if world == 1:
+            # the RCCL path of the library on this box: a one-rank communicator (ncclAllGather of one shard = a copy)
+            try:
+                from ses import HipES
+                solo = HipES(None, 4, 2, True, False)
+                solo.comm_init(0, 1, HipES.comm_unique_id())
+                shard_t = torch.rand(4096, device="cuda")
+                out = solo.allgather_fitness(shard_t)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(50):
+                    solo.allgather_fitness(shard_t, out=out)
+                e1.record()
+                e1.synchronize()
+                result["rccl_single_rank"] = {"rccl_version": solo.comm_info()[2], "ranks": 1, "bytes": 16384,
+                                              "allgather_us": e0.elapsed_time(e1) * 1e3 / 50,
+                                              "equal": bool(torch.equal(out, shard_t))}
+                solo.close()
+            except Exception as exc:
+                result["rccl_single_rank"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 from oracle import ref_port
@@ -253,7 +457,15 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
+    return 0
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn(args))
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

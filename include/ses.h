@@ -39,6 +39,7 @@ extern "C" {
 #define SES_ERR_UNSUPPORTED (-2)
 #define SES_ERR_HIP (-3)
 #define SES_ERR_NO_DEVICE (-4)
+#define SES_ERR_COMM (-5) /* RCCL not loadable, or a communicator call failed */
 
 #define SES_HIDDEN 32 /* hidden width, hard-coded in networks/neural_network.py:12-17 */
 
@@ -151,8 +152,11 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
 /* ---- K4: rank-centred fitness shaping (offspring_strategies.py:380-398) --------------------- */
 /* rank[i] = number of offspring that beat i (reward descending; ties: higher index first, i.e.
  * np.flip(np.argsort(kind="stable"))).  weights[i] = ((n-1-rank)/(n-1) - 0.5) / std, float64,
- * with the closed-form std sqrt((n+1)/(12(n-1))) of the rank grid.  weights may be NULL. */
-int ses_rank_center(ses_handle *h, const float *fitness, int32_t n, int32_t *rank, double *weights);
+ * with the closed-form std sqrt((n+1)/(12(n-1))) of the rank grid.  weights may be NULL.
+ * best (float32[1], may be NULL) receives the fitness of the offspring with rank 0, i.e. max(rewards): the
+ * `best_reward` that evaluate() returns (offspring_strategies.py:420-434), so that the host reads one float back
+ * instead of reducing the vector. */
+int ses_rank_center(ses_handle *h, const float *fitness, int32_t n, int32_t *rank, double *weights, float *best);
 
 /* ---- K5: ES gradient + Adam (offspring_strategies.py:400-416, optimizers.py:13-24,42-57) ---- */
 /*
@@ -193,6 +197,27 @@ int ses_elite_select(ses_handle *h, const int32_t *rank, int32_t n, int32_t k, c
 int ses_elite_mean(ses_handle *h, const float *rows, const int32_t *alias_first, int32_t k, float *mean);
 /* dst[i,:] = src[ids[i],:] */
 int ses_gather_rows(ses_handle *h, const float *src, const int32_t *ids, int32_t n_ids, float *dst);
+
+/* ---- multi-GPU: fitness all-gather over RCCL (replaces the gather half of Pool.map, loop.py:66-79) ---------- */
+/*
+ * The population shards over one process per GPU: rank r of W owns n_per_rank = ceil(N / W) consecutive global
+ * rows (the last rank pads its shard, e.g. with -inf).  The ONE exchange of a generation is the all-gather of the
+ * float32 fitness shards, N * 4 bytes (16 KB at N = 4096): latency-bound on xGMI, one ncclAllGather, no bucketing.
+ * Everything after it (rank shaping, ES update, elite rows) is recomputed identically on every rank from the
+ * counter-based noise, so there is no second collective.
+ *   ses_comm_unique_id : rank 0 fills id[SES_COMM_ID_BYTES] (ncclGetUniqueId); the host hands the bytes to the other
+ *                        ranks by whatever it has (a file, MPI, a torch.distributed store, ...).
+ *   ses_comm_init      : collective over the W ranks; binds an RCCL communicator for the handle's device to the handle.
+ *   ses_allgather_fitness : all[r * n_per_rank + i] = local_r[i] on every rank, enqueued on the handle's stream.
+ * RCCL (librccl.so.1) is loaded on the first ses_comm_* call; single-GPU users never load it.
+ */
+#define SES_COMM_ID_BYTES 128
+int ses_comm_unique_id(void *id);
+int ses_comm_init(ses_handle *h, int32_t rank, int32_t world, const void *id);
+/* rank / world of the handle's communicator (world = 0: none) and the RCCL version code; any pointer may be NULL */
+int ses_comm_info(ses_handle *h, int32_t *rank, int32_t *world, int32_t *rccl_version);
+int ses_comm_destroy(ses_handle *h); /* also done by ses_destroy */
+int ses_allgather_fitness(ses_handle *h, const float *local, int32_t n_per_rank, float *all);
 
 #ifdef __cplusplus
 }

@@ -8,5 +8,5 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 # and SLP packing adds v_mov traffic; measured 0.357 -> 0.311 ms on the 4096x5x500 rollout.
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fno-slp-vectorize
        -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I/opt/rocm/include)
-"$HIPCC" "${FLAGS[@]}" "$@" "$HERE/ses_core.hip" "$HERE/ses_rollout.hip" "$HERE/ses_strategy.hip" -o "$OUT"
+"$HIPCC" "${FLAGS[@]}" "$@" "$HERE/ses_core.hip" "$HERE/ses_rollout.hip" "$HERE/ses_strategy.hip" "$HERE/ses_comm.hip" -ldl -o "$OUT"
 echo "built $OUT"

@@ -117,6 +117,7 @@ int ses_destroy(ses_handle *h)
 {
     if (!h) return SES_OK;
     (void)hipSetDevice(h->cfg.device);
+    (void)ses::comm_release(h);
     if (h->ep_return) (void)hipFree(h->ep_return);
     if (h->ep_steps) (void)hipFree(h->ep_steps);
     if (h->red_scratch) (void)hipFree(h->red_scratch);

@@ -18,6 +18,9 @@ struct ses_handle {
     size_t ep_cap;       // capacity in episodes
     void *red_scratch;   // rank keys (u64[n]) followed by es_update partial sums
     size_t red_cap;      // bytes
+    // multi-GPU (ses_comm.hip): RCCL communicator of this rank, null until ses_comm_init
+    void *comm;
+    int comm_rank, comm_world;
 };
 
 namespace ses {
@@ -41,5 +44,6 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 int ensure_episode_scratch(ses_handle *h, size_t episodes);
 int ensure_reduce_scratch(ses_handle *h, size_t bytes);
+int comm_release(ses_handle *h);
 
 }  // namespace ses

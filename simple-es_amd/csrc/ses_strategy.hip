@@ -179,12 +179,16 @@ __global__ __launch_bounds__(256) void k_rank_search(const unsigned long long *_
 }
 
 __global__ __launch_bounds__(256) void k_rank_weights(const int32_t *__restrict__ rank, int n,
-                                                      double *__restrict__ weights)
+                                                      const float *__restrict__ fitness,
+                                                      double *__restrict__ weights, float *__restrict__ best)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const int r = rank[i];
+    if (best && r == 0) *best = fitness[i];                           // max(rewards), loop.py:82-84 `best_reward`
+    if (!weights) return;
     const double nm1 = (double)(n - 1);
-    const double centred = ((double)(n - 1 - rank[i]) / nm1) - 0.5;   // offspring_strategies.py:394-396
+    const double centred = ((double)(n - 1 - r) / nm1) - 0.5;         // offspring_strategies.py:394-396
     const double sd = sqrt((double)(n + 1) / (12.0 * nm1));           // closed-form std of the rank grid
     weights[i] = centred / sd;
 }
@@ -402,7 +406,7 @@ int ses_init_states_uniform(ses_handle *h, uint64_t seed, uint64_t gen, int64_t 
     return SES_OK;
 }
 
-int ses_rank_center(ses_handle *h, const float *fitness, int32_t n, int32_t *rank, double *weights)
+int ses_rank_center(ses_handle *h, const float *fitness, int32_t n, int32_t *rank, double *weights, float *best)
 {
     SES_REQUIRE(h && fitness && rank, "ses_rank_center: null argument");
     SES_REQUIRE(n >= 2, "ses_rank_center: need at least 2 offspring (the reference divides by n-1)");
@@ -425,8 +429,9 @@ int ses_rank_center(ses_handle *h, const float *fitness, int32_t n, int32_t *ran
         hipLaunchKernelGGL(k_rank_count, dim3(ceil_div(n, 256), ceil_div(n, jt)), dim3(256), 0, h->stream, keys, n,
                            (int)jt, rank);
     }
-    if (weights)
-        hipLaunchKernelGGL(k_rank_weights, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, rank, n, weights);
+    if (weights || best)
+        hipLaunchKernelGGL(k_rank_weights, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, rank, n, fitness, weights,
+                           best);
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;
 }

@@ -28,6 +28,8 @@ class GymWrapper:
             raise ValueError("env.physics must be 'float32' (default) or 'float64' (gym-order CartPole dynamics)")
         self.physics64 = physics == "float64"
         self.spec = SUPPORTED[name]
+        # a gym name that is served by a reduced model says so at run time (ESLoop prints it, metrics.jsonl records it)
+        self.variant = "lander-lite" if "LunarLander" in name else None
         # YAML `max_step: None` is the STRING "None" in the reference (gym_wrapper.py:37); accept both.
         limit = self.spec["time_limit"]
         self.max_step = max_step

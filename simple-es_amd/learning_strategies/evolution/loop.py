@@ -14,8 +14,10 @@ from collections import deque
 from datetime import datetime
 
 import torch
+import torch.distributed as dist
 
-from ses import HipES, MODE_EPISODIC
+from ses import HipES, MODE_EPISODIC, MODE_FIXED_LENGTH
+from ses.parallel import attach_comm
 
 from .abstracts import BaseESLoop
 
@@ -36,12 +38,30 @@ class ESLoop(BaseESLoop):
         self.save_model_period = save_model_period
         self.seed_env = int((config or {}).get("env", {}).get("seed", 0)) if isinstance(config, dict) else 0
         self.shared_init = bool((config or {}).get("env", {}).get("shared_init", False)) if isinstance(config, dict) else False
+        env_cfg = (config or {}).get("env", {}) if isinstance(config, dict) else {}
+        # env.fixed_length: the synchronous-benchmark mode of the rollout kernels (termination masked: finished envs
+        # keep stepping, rewards gated; identical returns, data-independent work).  Default: episodic, like the reference.
+        self.mode = MODE_FIXED_LENGTH if env_cfg.get("fixed_length", False) else MODE_EPISODIC
+        self.env_variant = getattr(env, "variant", None)     # e.g. "lander-lite": a reduced model stands in for the gym env
         self.history = []
         self._metrics = None
+        self._events = None
+        self._ev_k = 0
 
-        stamp = datetime.now().strftime("%Y%m%d%H%M%S")
-        self.save_dir = f"logs/{self.env.name}/{stamp}"
-        os.makedirs(self.save_dir + "/saved_models/", exist_ok=True)
+        # logs/<env>/<timestamp>[_k]: the reference's makedirs (loop.py:40-47) raises when two loops start in the same
+        # second; here the second one gets a suffix instead of silently sharing the directory.  Only rank 0 writes.
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        self.save_dir = None
+        if rank == 0:
+            stamp = datetime.now().strftime("%Y%m%d%H%M%S")
+            base, k = f"logs/{self.env.name}/{stamp}", 0
+            while True:
+                self.save_dir = base if k == 0 else f"{base}_{k}"
+                try:
+                    os.makedirs(self.save_dir + "/saved_models/", exist_ok=False)
+                    break
+                except FileExistsError:
+                    k += 1
 
         if self.log:
             import wandb                          # optional dependency, only when --log is given
@@ -50,59 +70,102 @@ class ESLoop(BaseESLoop):
         self.dev = HipES(env.name, network.num_state, network.num_action, network.discrete_action, network.use_gru,
                          pomdp=env.pomdp, max_step=env.horizon, eval_ep_num=eval_ep_num,
                          n_agents=getattr(env, "n_agents", 1), physics64=getattr(env, "physics64", False))
+        attach_comm(self.dev)      # multi-GPU: the fitness all-gather runs on this handle's RCCL communicator
+        self._events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
 
     # the rollout phase of one generation: Population -> float32[N] fitness (identical on every rank)
     def rollout(self, population):
         shard = population.shard
         if self.shared_init:                       # common random numbers: every offspring sees the same resets
-            init = self.dev.init_states_uniform(self.seed_env, population.gen, 0, 1, shared=True)[0].contiguous()
+            init = self.dev.init_states_uniform(self.seed_env, population.gen, 0, 1, shared=True)[0]
         else:                                      # reference behaviour: independent resets per offspring
             init = self.dev.init_states_uniform(self.seed_env, population.gen, shard.first, max(shard.n_local, 1))
-            init = init[: shard.n_local].contiguous()
-        local = self.dev.rollout(population.theta, init, mode=MODE_EPISODIC) if shard.n_local else self.dev.empty(0)
-        return shard.allgather_fitness(local)
+            if shard.n_local != init.shape[0]:
+                init = init[: shard.n_local].contiguous()
+        local = self.dev.rollout(population.theta, init, mode=self.mode) if shard.n_local else self.dev.empty(0)
+        return shard.allgather_fitness(local, dev=self.dev)
+
+    def generation(self, offsprings):
+        """Enqueue one whole generation -- rollout of this rank's shard, fitness all-gather, strategy.evaluate with
+        the next population -- WITHOUT waiting for the GPU.  Returns (next offspring group, best reward as a
+        PendingReward, sigma, (event before, event after the rollout phase)).  run() is a loop of this plus the
+        reference's logging; bench.py times exactly this method."""
+        ev0, ev1 = self._events[self._ev_k]
+        self._ev_k = (self._ev_k + 1) % len(self._events)
+        ev0.record()
+        results = self.rollout(offsprings)
+        ev1.record()
+        strategy = self.offspring_strategy
+        if hasattr(strategy, "evaluate_async"):
+            offsprings, best, curr_sigma = strategy.evaluate_async(results)
+        else:                                      # a user strategy with the reference's synchronous evaluate() only
+            offsprings, value, curr_sigma = strategy.evaluate(results)
+            best = _Ready(value)
+        return offsprings, best, curr_sigma, (ev0, ev1)
+
+    def _report(self, ep_num, best, curr_sigma, events, start_time, rank0):
+        """The reference's per-generation bookkeeping (loop.py:85-99) for a generation whose results are in."""
+        best_reward = best.result()                # waits for THAT generation only; the next one is already queued
+        now = time.time()
+        consumed_time = now - max(start_time, self._last_report)    # generations overlap: time between completions
+        self._last_report = now
+        rollout_consumed_time = events[0].elapsed_time(events[1]) * 1e-3   # GPU time of the rollout phase (HIP events)
+        eval_consumed_time = max(consumed_time - rollout_consumed_time, 0.0)
+        self.history.append((best_reward, curr_sigma))
+        self.ep5_rewards.append(best_reward)
+        if not rank0:
+            return
+        ep5 = sum(self.ep5_rewards) / len(self.ep5_rewards)
+        if self._metrics is None:                  # wandb-free metrics: same quantities as loop.py:94-99
+            self._metrics = open(self.save_dir + "/metrics.jsonl", "a", buffering=1 << 16)
+            if self.env_variant:
+                self._metrics.write(json.dumps({"env_variant": self.env_variant}) + "\n")
+        self._metrics.write(json.dumps({"episode": ep_num, "best_reward": best_reward, "curr_sigma": curr_sigma,
+                                        "ep5_mean_reward": ep5, "time": consumed_time,
+                                        "rollout_t": rollout_consumed_time, "eval_t": eval_consumed_time}) + "\n")
+        print(f"episode: {ep_num}, Best reward: {best_reward:.2f}, sigma: {curr_sigma:.3f}, "
+              f"time: {consumed_time:.2f}, rollout_t: {rollout_consumed_time:.2f}, "
+              f"eval_t: {eval_consumed_time:.2f}")
+        if self.log:
+            import wandb
+            wandb.log({"ep5_mean_reward": ep5, "curr_sigma": curr_sigma})
 
     def run(self):
+        """The reference's generation loop (loop.py:52-104).  The host stays one generation ahead of the GPU: the
+        prints / metrics of generation g are produced while generation g + 1 is running, so the device never waits
+        for Python.  Every printed value is the one the reference would print for that generation."""
         offsprings = self.offspring_strategy.init_offspring(self.network, self.env.get_agent_ids())
         rank0 = offsprings.shard.rank == 0
-        ep_num = 0
-        for _ in range(self.generation_num):
+        if rank0 and self.env_variant:
+            print(f"note: {self.env.name} runs on the {self.env_variant} model of this build (see README: not Box2D)")
+        pending = None
+        self._last_report = 0.0
+        for ep_num in range(1, self.generation_num + 1):
             start_time = time.time()
-            ep_num += 1
+            offsprings, best, curr_sigma, events = self.generation(offsprings)
+            if pending is not None:
+                self._report(*pending, rank0)
+            pending = (ep_num, best, curr_sigma, events, start_time)
+            if ep_num % self.save_model_period == 0:
+                self._report(*pending, rank0)      # a checkpoint generation is reported before its file is written
+                pending = None
+                if rank0:
+                    elite = self.offspring_strategy.get_elite_model()
+                    torch.save(elite.state_dict(), self.save_dir + "/saved_models" + f"/ep_{ep_num}.pt")
+                    self._metrics.flush()
+        if pending is not None:
+            self._report(*pending, rank0)
+        if self._metrics is not None:
+            self._metrics.flush()
+        return offsprings
 
-            # rollout_t is the GPU time of the rollout phase (HIP events, no host wait); evaluate() ends with the one
-            # device read-back of a generation (best reward), so eval_t = everything else in the wall time
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-            results = self.rollout(offsprings)
-            ev1.record()
-            offsprings, best_reward, curr_sigma = self.offspring_strategy.evaluate(results)
-            ev1.synchronize()
-            consumed_time = time.time() - start_time
-            rollout_consumed_time = ev0.elapsed_time(ev1) * 1e-3
-            eval_consumed_time = max(consumed_time - rollout_consumed_time, 0.0)
-            self.history.append((best_reward, curr_sigma))
-            self.ep5_rewards.append(best_reward)
-            if rank0:                                   # wandb-free metrics: same quantities as loop.py:94-99
-                if self._metrics is None:
-                    self._metrics = open(self.save_dir + "/metrics.jsonl", "a", buffering=1)   # line-buffered
-                self._metrics.write(json.dumps({"episode": ep_num, "best_reward": best_reward, "curr_sigma": curr_sigma,
-                                                "ep5_mean_reward": sum(self.ep5_rewards) / len(self.ep5_rewards),
-                                                "time": consumed_time, "rollout_t": rollout_consumed_time,
-                                                "eval_t": eval_consumed_time}) + "\n")
-            if rank0:
-                print(f"episode: {ep_num}, Best reward: {best_reward:.2f}, sigma: {curr_sigma:.3f}, "
-                      f"time: {consumed_time:.2f}, rollout_t: {rollout_consumed_time:.2f}, "
-                      f"eval_t: {eval_consumed_time:.2f}")
 
-            if self.log and rank0:
-                import wandb
-                wandb.log({"ep5_mean_reward": sum(self.ep5_rewards) / len(self.ep5_rewards),
-                           "curr_sigma": curr_sigma})
+class _Ready:
+    def __init__(self, value):
+        self._value = float(value)
 
-            if ep_num % self.save_model_period == 0 and rank0:
-                elite = self.offspring_strategy.get_elite_model()
-                torch.save(elite.state_dict(), self.save_dir + "/saved_models" + f"/ep_{ep_num}.pt")
+    def result(self):
+        return self._value
 
 
 def RolloutWorker(arguments):

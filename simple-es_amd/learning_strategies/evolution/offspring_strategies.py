@@ -58,6 +58,36 @@ class Population:
         return (self[i] for i in range(self.shard.first, self.shard.first + self.shard.n_local))
 
 
+class PendingReward:
+    """best_reward of a generation, read back without stalling the thread that enqueues the next one: the float is
+    copied into pinned host memory behind the kernels that produce it, result() waits for that copy alone."""
+
+    def __init__(self, host, event):
+        self._host, self._event, self._value = host, event, None
+
+    def result(self):
+        if self._value is None:
+            self._event.synchronize()
+            self._value = float(self._host[0])
+        return self._value
+
+
+class _ReadbackRing:
+    """`depth` pinned host slots + events, reused round-robin (the loop keeps at most two generations in flight)."""
+
+    def __init__(self, device, depth=4):
+        self.best = torch.zeros(1, dtype=torch.float32, device=device)      # written by ses_rank_center
+        self.slots = [(torch.zeros(1, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(depth)]
+        self.k = 0
+
+    def push(self):
+        host, event = self.slots[self.k]
+        self.k = (self.k + 1) % len(self.slots)
+        host.copy_(self.best, non_blocking=True)
+        event.record()
+        return PendingReward(host, event)
+
+
 class _DeviceStrategy(BaseOffspringStrategy):
     def __init__(self, init_sigma, sigma_decay, offspring_num, noise, seed):
         if noise not in ("philox", "numpy"):
@@ -79,6 +109,27 @@ class _DeviceStrategy(BaseOffspringStrategy):
         network.zero_init()           # every strategy starts from the zero network (offspring_strategies.py:83,200,348)
         self.dev = HipES(None, network.num_state, network.num_action, network.discrete_action, network.use_gru)
         self.P = self.dev.P
+        self._ring = _ReadbackRing(self.dev.device)
+        self._shards = {}
+
+    def _shard(self, n):
+        sh = self._shards.get(n)
+        if sh is None:
+            sh = self._shards[n] = Shard(n)
+        return sh
+
+    def _const_map(self, key, build):
+        """The parent map of a strategy depends only on (elite_num, offspring_num): built once, so that the identity
+        checks of the upload caches below hit every generation."""
+        maps = self.__dict__.setdefault("_maps", {})
+        if key not in maps:
+            maps[key] = build()
+        return maps[key]
+
+    def evaluate(self, rewards):
+        """(offspring_group, best_reward, curr_sigma) like the reference; best_reward is read back here."""
+        pop, best, sigma = self.evaluate_async(rewards)
+        return pop, best.result(), sigma
 
     def _population_size(self):
         raise NotImplementedError
@@ -86,18 +137,20 @@ class _DeviceStrategy(BaseOffspringStrategy):
     def _materialise(self, parents, parent_idx_host, sigma):
         """Build this rank's rows of the population described by (parents[K,P], parent_idx[N])."""
         n = len(parent_idx_host)
-        shard = Shard(n)
+        shard = self._shard(n)
         if self.noise == "numpy" and shard.world != 1:
             raise RuntimeError("noise='numpy' reproduces the reference's single global stream: run it on one process")
         lo, hi = shard.first, shard.first + shard.n_local
-        local_idx = np.ascontiguousarray(parent_idx_host[lo:hi], dtype=np.int32)
         cached = getattr(self, "_idx_cache", None)     # the parent map is the same every generation: upload it once
-        if cached is None or cached[0].shape != local_idx.shape or not np.array_equal(cached[0], local_idx):
-            cached = (local_idx.copy(), torch.from_numpy(local_idx).to(self.dev.device))
+        if cached is None or cached[2] is not parent_idx_host:
+            local_idx = np.ascontiguousarray(parent_idx_host[lo:hi], dtype=np.int32)
+            if cached is None or cached[0].shape != local_idx.shape or not np.array_equal(cached[0], local_idx):
+                cached = (local_idx.copy(), torch.from_numpy(local_idx).to(self.dev.device), parent_idx_host)
+            else:
+                cached = (cached[0], cached[1], parent_idx_host)
             self._idx_cache = cached
         idx = cached[1]
-        self._last = {"parents": parents, "idx_host": np.asarray(parent_idx_host, dtype=np.int32), "sigma": sigma,
-                      "gen": self.gen, "shard": shard}
+        self._last = {"parents": parents, "idx_host": parent_idx_host, "sigma": sigma, "gen": self.gen, "shard": shard}
         if shard.n_local == 0:                      # more ranks than offspring: this rank idles through the rollout
             theta = self.dev.empty(0, self.P)
         elif self.noise == "philox":
@@ -133,9 +186,9 @@ class _DeviceStrategy(BaseOffspringStrategy):
         """Elite ids, their rows and (simple_evolution) the aliasing flags without a host round trip: one
         ses_elite_select launch on the rank vector and the device copy of the current parent map."""
         last = self._last
-        cached = getattr(self, "_map_dev", None)
-        if cached is None or cached[0] is not last["idx_host"]:
-            cached = (last["idx_host"], torch.from_numpy(np.ascontiguousarray(last["idx_host"])).to(self.dev.device))
+        cached = getattr(self, "_map_dev", None)          # whole-population map on the device, uploaded once
+        if cached is None or (cached[0] is not last["idx_host"] and not np.array_equal(cached[0], last["idx_host"])):
+            cached = (last["idx_host"], torch.from_numpy(np.ascontiguousarray(last["idx_host"], dtype=np.int32)).to(self.dev.device))
             self._map_dev = cached
         ids, sel, alias = self.dev.elite_select(rank, k, cached[1], alias_state)
         self._elite_ids_dev = ids
@@ -152,6 +205,9 @@ class _DeviceStrategy(BaseOffspringStrategy):
         return None if self._elite_ids_dev is None else self._elite_ids_dev.cpu().numpy()
 
     def _fitness_tensor(self, rewards):
+        if (isinstance(rewards, torch.Tensor) and rewards.dtype == torch.float32 and rewards.device == self.dev.device
+                and rewards.is_contiguous() and rewards.numel() == self._population_size()):
+            return rewards.view(-1)
         if isinstance(rewards, torch.Tensor):
             fit = rewards.to(device=self.dev.device, dtype=torch.float32).contiguous()
         else:
@@ -175,12 +231,14 @@ class simple_genetic(_DeviceStrategy):
         return self.elite_num * (self.offspring_num // self.elite_num)
 
     def _gen_offsprings(self, agent_ids, elite_models, elite_num, offspring_num, sigma):
-        per = offspring_num // elite_num
-        idx = np.empty(elite_num * per, dtype=np.int32)
-        for e in range(elite_num):
-            idx[e * per] = -1 - e                 # the elite itself, verbatim
-            idx[e * per + 1:(e + 1) * per] = e    # its children
-        return self._materialise(elite_models, idx, sigma)
+        def build():
+            per = offspring_num // elite_num
+            idx = np.empty(elite_num * per, dtype=np.int32)
+            for e in range(elite_num):
+                idx[e * per] = -1 - e                 # the elite itself, verbatim
+                idx[e * per + 1:(e + 1) * per] = e    # its children
+            return idx
+        return self._materialise(elite_models, self._const_map(("genetic", elite_num, offspring_num), build), sigma)
 
     def get_elite_model(self):
         return self._model_from(self.elite_models[0])
@@ -190,16 +248,16 @@ class simple_genetic(_DeviceStrategy):
         self.elite_models = self.dev.zeros(self.elite_num, self.P)
         return self._gen_offsprings(agent_ids, self.elite_models, self.elite_num, self.offspring_num, self.curr_sigma)
 
-    def evaluate(self, rewards):
+    def evaluate_async(self, rewards):
+        """evaluate() without the read-back: best_reward comes as a PendingReward (result() waits for it)."""
         fit = self._fitness_tensor(rewards)
-        rank, _ = self.dev.rank_center(fit)
-        best = fit.max()
+        rank, _ = self.dev.rank_center(fit, want_weights=False, best=self._ring.best)
+        best = self._ring.push()
         self.elite_models, _ = self._select_elites(rank, self.elite_num)
         pop = self._gen_offsprings(self.agent_ids, self.elite_models, self.elite_num, self.offspring_num,
                                    self.curr_sigma)
         self.curr_sigma *= self.sigma_decay       # decays AFTER regeneration (offspring_strategies.py:117-124)
-        best_reward = float(best.item())          # the only synchronisation point of a generation
-        return pop, best_reward, self.curr_sigma
+        return pop, best, self.curr_sigma
 
     def get_wandb_cfg(self):
         return dict(init_sigma=self.init_sigma, sigma_decay=self.sigma_decay, elite_num=self.elite_num,
@@ -219,9 +277,12 @@ class simple_evolution(_DeviceStrategy):
 
     def _gen_offsprings(self, agent_ids, elite_models, mu_model, sigma, offspring_num):
         parents = torch.stack([mu_model, elite_models]).contiguous()
-        idx = np.zeros(offspring_num + 1, dtype=np.int32)
-        idx[0], idx[1] = -1, -2                   # [mu, elite0, then N-1 children of mu]
-        return self._materialise(parents, idx, sigma)
+
+        def build():
+            idx = np.zeros(offspring_num + 1, dtype=np.int32)
+            idx[0], idx[1] = -1, -2               # [mu, elite0, then N-1 children of mu]
+            return idx
+        return self._materialise(parents, self._const_map(("evolution", offspring_num), build), sigma)
 
     def get_elite_model(self):
         return self._model_from(self.elite0)
@@ -233,10 +294,11 @@ class simple_evolution(_DeviceStrategy):
         self._alias_state = torch.ones(1, dtype=torch.int32, device=self.dev.device)
         return self._gen_offsprings(agent_ids, self.elite0, self.mu_model, self.curr_sigma, self.offspring_num)
 
-    def evaluate(self, rewards):
+    def evaluate_async(self, rewards):
+        """evaluate() without the read-back: best_reward comes as a PendingReward (result() waits for it)."""
         fit = self._fitness_tensor(rewards)
-        rank, _ = self.dev.rank_center(fit)
-        best = fit.max()
+        rank, _ = self.dev.rank_center(fit, want_weights=False, best=self._ring.best)
+        best = self._ring.push()
         # the reference sums the elites IN PLACE into elite[0]; an elite that is the same object as elite[0]
         # (slots 0 and 1 while they alias) doubles the running sum instead of adding its own value: the flags and
         # the aliasing state are kept on the device by ses_elite_select (include/ses.h)
@@ -246,8 +308,7 @@ class simple_evolution(_DeviceStrategy):
         self.elite0 = mean                         # elite[0] was overwritten with the mean (aliasing quirk)
         self.curr_sigma *= self.sigma_decay
         pop = self._gen_offsprings(self.agent_ids, self.elite0, self.mu_model, self.curr_sigma, self.offspring_num)
-        best_reward = float(best.item())           # the only synchronisation point of a generation
-        return pop, best_reward, self.curr_sigma
+        return pop, best, self.curr_sigma
 
     def get_wandb_cfg(self):
         return dict(init_sigma=self.init_sigma, elite_num=self.elite_num, offspring_num=self.offspring_num)
@@ -264,9 +325,11 @@ class openai_es(_DeviceStrategy):
         return self.offspring_num
 
     def _gen_offsprings(self, agent_ids, mu_model, sigma, offspring_num):
-        idx = np.zeros(offspring_num, dtype=np.int32)
-        idx[0] = -1                               # member 0 is the unperturbed mu (epsilon = 0)
-        return self._materialise(mu_model.view(1, -1), idx, sigma)
+        def build():
+            idx = np.zeros(offspring_num, dtype=np.int32)
+            idx[0] = -1                           # member 0 is the unperturbed mu (epsilon = 0)
+            return idx
+        return self._materialise(mu_model.view(1, -1), self._const_map(("openai", offspring_num), build), sigma)
 
     def get_elite_model(self):
         return self._model_from(self.mu_model)
@@ -277,10 +340,11 @@ class openai_es(_DeviceStrategy):
         self.optimizer = Adam(self.mu_model, self.learning_rate)
         return self._gen_offsprings(agent_ids, self.mu_model, self.curr_sigma, self.offspring_num)
 
-    def evaluate(self, rewards):
+    def evaluate_async(self, rewards):
+        """evaluate() without the read-back: best_reward comes as a PendingReward (result() waits for it)."""
         fit = self._fitness_tensor(rewards)
-        _, weights = self.dev.rank_center(fit)
-        best = fit.max()                          # read back at the very end: nothing below waits for the GPU
+        _, weights = self.dev.rank_center(fit, best=self._ring.best)
+        best = self._ring.push()                  # copied to pinned memory in stream order: nothing here waits
         a = self.optimizer.next_step_scale()
         opt = self.optimizer
         if self.noise == "philox":
@@ -291,8 +355,7 @@ class openai_es(_DeviceStrategy):
                                       self.mu_model, opt.m, opt.v)
         self.curr_sigma *= self.sigma_decay
         pop = self._gen_offsprings(self.agent_ids, self.mu_model, self.curr_sigma, self.offspring_num)
-        best_reward = float(best.item())          # the only synchronisation point of a generation
-        return pop, best_reward, self.curr_sigma
+        return pop, best, self.curr_sigma
 
     def get_wandb_cfg(self):
         return dict(init_sigma=self.init_sigma, sigma_decay=self.sigma_decay, learning_rate=self.learning_rate,

@@ -59,14 +59,20 @@ SIGNATURES = {
     "ses_policy_forward": [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "ses_env_step": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ses_rollout": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
-    "ses_rank_center": [_vp, _vp, _i32, _vp, _vp],
+    "ses_rank_center": [_vp, _vp, _i32, _vp, _vp, _vp],
     "ses_es_update_philox": [_vp, _vp, _i32, _i32, _u64, _u64, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
     "ses_es_update_stored": [_vp, _vp, _i32, _vp, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
     "ses_elite_ids": [_vp, _vp, _i32, _i32, _vp],
     "ses_elite_select": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "ses_elite_mean": [_vp, _vp, _vp, _i32, _vp],
     "ses_gather_rows": [_vp, _vp, _vp, _i32, _vp],
+    "ses_comm_unique_id": [_vp],
+    "ses_comm_init": [_vp, _i32, _i32, _vp],
+    "ses_comm_info": [_vp, _vp, _vp, _vp],
+    "ses_comm_destroy": [_vp],
+    "ses_allgather_fitness": [_vp, _vp, _i32, _vp],
 }
+COMM_ID_BYTES = 128
 _RESTYPE = {"ses_last_error": ctypes.c_char_p, "ses_version": ctypes.c_char_p}
 
 _lib = None

@@ -90,6 +90,17 @@ class HipES:
             raise SesError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
         return t
 
+    def _check_parent_idx(self, parent_idx, K):
+        """-K <= parent_idx < K, or raise.  The check reads the tensor back (a device sync), so its result is cached --
+        on the tensor OBJECT (held here, so its address cannot be recycled for another tensor) and its version."""
+        last = getattr(self, "_idx_checked", None)
+        if last is not None and last[0] is parent_idx and last[1] == parent_idx._version and last[2] == K:
+            return
+        lo, hi = int(parent_idx.min()), int(parent_idx.max())
+        if hi >= K or lo < -K:
+            raise SesError(f"parent_idx outside [-{K}, {K})")
+        self._idx_checked = (parent_idx, parent_idx._version, K)
+
     def empty(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
@@ -110,6 +121,40 @@ class HipES:
     def sync(self):
         check(self._lib.ses_sync(self._h), "ses_sync")
 
+    # -- multi-GPU: RCCL communicator owned by the handle (include/ses.h, ses_comm_*) -------------
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes from ncclGetUniqueId; rank 0 creates them, every rank passes them to comm_init."""
+        buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+        check(_lib.load().ses_comm_unique_id(buf), "ses_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise SesError(f"comm_init: unique id must be {_lib.COMM_ID_BYTES} bytes")
+        buf = ctypes.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
+        check(self._lib.ses_comm_init(self._h, int(rank), int(world), buf), "ses_comm_init")
+
+    def comm_info(self):
+        """(rank, world, rccl_version_code); world == 0 means the handle has no communicator."""
+        r, w, v = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        check(self._lib.ses_comm_info(self._h, ctypes.byref(r), ctypes.byref(w), ctypes.byref(v)), "ses_comm_info")
+        return r.value, w.value, v.value
+
+    def comm_destroy(self):
+        check(self._lib.ses_comm_destroy(self._h), "ses_comm_destroy")
+
+    def allgather_fitness(self, local, out=None):
+        """local float32[n_per_rank] on every rank -> float32[world * n_per_rank], rank-major, identical everywhere."""
+        _, world, _ = self.comm_info()
+        if world < 1:
+            raise SesError("allgather_fitness: the handle has no communicator (comm_init first)")
+        n = local.shape[0]
+        self._chk(local, "local", torch.float32, (n,))
+        out = self.empty(world * n) if out is None else self._chk(out, "all", torch.float32, (world * n,))
+        check(self._lib.ses_allgather_fitness(self._h, _ptr(local), int(n), _ptr(out)), "ses_allgather_fitness")
+        return out
+
     # -- K1 -----------------------------------------------------------------------------------
     def perturb(self, parents, sigma, seed, gen, first_row, n_rows, parent_idx=None, row_ids=None, out=None,
                 idx_in_range=False):
@@ -121,13 +166,7 @@ class HipES:
         self._chk(parent_idx, "parent_idx", torch.int32, (n_rows,), optional=True)
         self._chk(row_ids, "row_ids", torch.int32, (n_rows,), optional=True)
         if parent_idx is not None and not idx_in_range:
-            # the range check reads the tensor back (a device sync): once per (tensor, version, K), not per generation
-            key = (parent_idx.data_ptr(), parent_idx._version, parent_idx.numel(), K)
-            if getattr(self, "_idx_checked", None) != key:
-                lo, hi = int(parent_idx.min()), int(parent_idx.max())
-                if hi >= K or lo < -K:
-                    raise SesError(f"parent_idx outside [-{K}, {K})")
-                self._idx_checked = key
+            self._check_parent_idx(parent_idx, K)
         theta = self.empty(n_rows, self.P) if out is None else self._chk(out, "theta", torch.float32, (n_rows, self.P))
         check(self._lib.ses_perturb(self._h, _ptr(parents), _ptr(parent_idx), _ptr(row_ids), float(sigma), int(seed),
                                     int(gen), int(first_row), int(n_rows), _ptr(theta)), "ses_perturb")
@@ -146,13 +185,7 @@ class HipES:
         self._chk(eps64, "eps64", torch.float64, (n_rows, self.P))
         self._chk(parent_idx, "parent_idx", torch.int32, (n_rows,), optional=True)
         if parent_idx is not None:
-            # the range check reads the tensor back (a device sync): once per (tensor, version, K), not per generation
-            key = (parent_idx.data_ptr(), parent_idx._version, parent_idx.numel(), K)
-            if getattr(self, "_idx_checked", None) != key:
-                lo, hi = int(parent_idx.min()), int(parent_idx.max())
-                if hi >= K or lo < -K:
-                    raise SesError(f"parent_idx outside [-{K}, {K})")
-                self._idx_checked = key
+            self._check_parent_idx(parent_idx, K)
         theta = self.empty(n_rows, self.P)
         store = self.empty(n_rows, self.P) if want_eps_store else None
         check(self._lib.ses_perturb_host_noise(self._h, _ptr(parents), _ptr(parent_idx), _ptr(eps64), float(sigma),
@@ -209,12 +242,16 @@ class HipES:
         return (fitness, ep_ret, ep_steps) if want_episodes else fitness
 
     # -- K4 / K5 / K6 -------------------------------------------------------------------------
-    def rank_center(self, fitness):
+    def rank_center(self, fitness, want_weights=True, best=None):
+        """rank int32[n], weights float64[n] (None when want_weights is False).  best: optional float32[1] device
+        tensor that receives max(fitness) in the same launch."""
         n = fitness.shape[0]
         self._chk(fitness, "fitness", torch.float32, (n,))
+        self._chk(best, "best", torch.float32, (1,), optional=True)
         rank = self.empty(n, dtype=torch.int32)
-        weights = self.empty(n, dtype=torch.float64)
-        check(self._lib.ses_rank_center(self._h, _ptr(fitness), int(n), _ptr(rank), _ptr(weights)), "ses_rank_center")
+        weights = self.empty(n, dtype=torch.float64) if want_weights else None
+        check(self._lib.ses_rank_center(self._h, _ptr(fitness), int(n), _ptr(rank), _ptr(weights), _ptr(best)),
+              "ses_rank_center")
         return rank, weights
 
     def es_update_philox(self, weights, seed, gen, lr, sigma, adam_a, mu, m, v, skip_row0=True, want_grad=False):

@@ -1,0 +1,118 @@
+"""The fitness all-gather of the C ABI (ses_comm_* / ses_allgather_fitness, RCCL on the handle's stream).
+
+On the 1-GPU test box RCCL can only form a one-rank communicator (it refuses two ranks on one device), which still
+runs the library's whole RCCL path -- dlopen, ncclGetUniqueId, ncclCommInitRank, ncclAllGather on the handle's
+stream, ncclCommDestroy.  With two or more GPUs visible the second test runs the sharded generation loop over a real
+two-rank communicator and compares it bit for bit with one rank."""
+import ctypes
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "simple-es_amd")
+
+
+def test_single_rank_rccl_communicator_roundtrip():
+    from ses import HipES, SesError
+    es = HipES(None, 4, 2, True, False)
+    assert es.comm_info()[1] == 0                                    # no communicator yet
+    shard = torch.rand(4096, device="cuda")
+    with pytest.raises(SesError, match="no communicator"):
+        es.allgather_fitness(shard)
+    uid = HipES.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    with pytest.raises(SesError):
+        es.comm_init(1, 1, uid)                                      # rank outside [0, world)
+    es.comm_init(0, 1, uid)
+    rank, world, version = es.comm_info()
+    assert (rank, world) == (0, 1) and version >= 20000
+    with pytest.raises(SesError, match="already has a communicator"):
+        es.comm_init(0, 1, uid)
+    out = es.allgather_fitness(shard)
+    es.sync()
+    assert torch.equal(out, shard)
+    for n in (1, 7, 513, 65536):                                     # C2 shard = 512..4096 floats, C4 total = 65536
+        s = torch.rand(n, device="cuda")
+        assert torch.equal(es.allgather_fitness(s), s)
+    es.comm_destroy()
+    assert es.comm_info()[1] == 0
+    es.close()
+
+
+def test_raw_abi_comm_error_paths():
+    from ses import _lib
+    lib = _lib.load()
+    cfg = _lib.SesConfig(-1, 4, 2, 1, 0, 0, 500, 5, 0, 0, 1, 0)
+    h = ctypes.c_void_p()
+    assert lib.ses_create(ctypes.byref(cfg), None, ctypes.byref(h)) == 0
+    buf = ctypes.create_string_buffer(128)
+    assert lib.ses_comm_unique_id(None) == -1
+    assert lib.ses_comm_init(h, 0, 0, buf) == -1                     # world < 1
+    assert lib.ses_comm_init(None, 0, 1, buf) == -1
+    x = torch.zeros(8, device="cuda")
+    assert lib.ses_allgather_fitness(h, ctypes.c_void_p(x.data_ptr()), 8, ctypes.c_void_p(x.data_ptr())) == -1
+    assert b"no communicator" in lib.ses_last_error()
+    assert lib.ses_destroy(h) == 0
+
+
+WORKER = textwrap.dedent("""
+    import contextlib, io, os, sys
+    import numpy as np, torch
+    sys.path[:0] = [%r, %r]
+    out_dir, world = sys.argv[1], int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        local = int(os.environ["LOCAL_RANK"])
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import builder
+    os.chdir(out_dir)
+    for name, n in (("openai_es", 203), ("simple_evolution", 96), ("simple_genetic", 120)):
+        cfg = {"env": {"name": "CartPole-v1", "max_step": 200, "pomdp": False, "seed": 3},
+               "network": {"name": "gym_model", "num_state": 4, "num_action": 2, "discrete_action": True, "gru": False},
+               "strategy": {"name": name, "init_sigma": 0.5, "sigma_decay": 0.99, "learning_rate": 0.05,
+                            "elite_num": 8, "offspring_num": n, "seed": 5}}
+        loop = builder.build_loop(cfg, 4, 1, 3, False, 10 ** 9)
+        assert loop.dev.comm_info()[1] == (world if world > 1 else 0)
+        fits = []
+        orig = loop.rollout
+        loop.rollout = lambda pop, _o=orig: (fits.append(_o(pop).cpu().numpy().copy()) or torch.from_numpy(fits[-1]).cuda())
+        with contextlib.redirect_stdout(io.StringIO()):
+            loop.run()
+        rank = int(os.environ.get("RANK", "0"))
+        elite = loop.offspring_strategy.get_elite_model().flat()
+        np.savez(os.path.join(out_dir, f"{name}_w{world}_r{rank}.npz"), fits=np.stack(fits), elite=elite,
+                 best=np.array([b for b, _ in loop.history]))
+    if world > 1:
+        dist.destroy_process_group()
+""")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_two_gpus_over_rccl_equal_one_gpu_bitwise(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % (ROOT, SRC))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    one = subprocess.run([sys.executable, str(script), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stdout + one.stderr
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), str(tmp_path)],
+                         capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stdout + two.stderr
+    for name in ("openai_es", "simple_evolution", "simple_genetic"):
+        ref = np.load(tmp_path / f"{name}_w1_r0.npz")
+        for r in (0, 1):
+            got = np.load(tmp_path / f"{name}_w2_r{r}.npz")
+            assert np.array_equal(got["fits"].view(np.uint32), ref["fits"].view(np.uint32)), (name, r, "fitness")
+            assert np.array_equal(got["elite"].view(np.uint32), ref["elite"].view(np.uint32)), (name, r, "elite")
+            assert np.array_equal(got["best"], ref["best"])

@@ -2,6 +2,7 @@
 generation loop must give every rank the identical fitness vector and parent, bit-equal to a single-rank run.
 This is the population-sharding path that bench.py --gpus N / run_es.py use over RCCL on a multi-GPU node."""
 import os
+import socket
 import subprocess
 import sys
 import textwrap
@@ -43,13 +44,19 @@ WORKER = textwrap.dedent("""
 """)
 
 
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_two_ranks_equal_one_rank_bitwise(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(WORKER % (ROOT, SRC))
     one = subprocess.run([sys.executable, str(script), str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stdout + one.stderr
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29544", str(script), str(tmp_path)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script), str(tmp_path)],
                          capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stdout + two.stderr
     for name in ("openai_es", "simple_evolution", "simple_genetic"):

@@ -493,7 +493,7 @@ def test_raw_c_abi_error_paths(es):
     assert lib.ses_rollout(h, p(t), p(i), 0, 8, 7, p(f), None, None) == -1            # unknown mode
     assert b"bad mode" in lib.ses_last_error()
     r = torch.zeros(1, dtype=torch.int32, device="cuda")
-    assert lib.ses_rank_center(h, p(f), 1, p(r), None) == -1                          # n - 1 = 0 divides in the reference
+    assert lib.ses_rank_center(h, p(f), 1, p(r), None, None) == -1                          # n - 1 = 0 divides in the reference
     assert lib.ses_elite_ids(h, p(r), 1, 2, p(r)) == -1                               # k > n
     bad = _lib.SesConfig(0, 5, 2, 1, 0, 0, 500, 5, 0, 0, 1, 0)                           # CartPole with num_state 5
     out = ctypes.c_void_p()

@@ -5,11 +5,20 @@ import subprocess
 import sys
 import textwrap
 
+import json
+import socket
+
 import pytest
 import yaml
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "simple-es_amd")
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def test_shard_partition_covers_population_exactly():
@@ -49,10 +58,30 @@ def test_fitness_allgather_world_size_2_gloo(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(WORKER % SRC)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), str(tmp_path)]
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script), str(tmp_path)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: the parent starts torch.distributed.run as a child, relays
+    rank 0's JSON line and returns the child's exit code (here the ranks only rendezvous: no GPU in this container)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                         capture_output=True, text=True, timeout=240, cwd=str(tmp_path),
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    assert json.loads(line) == {"rendezvous": "ok", "world": 2, "ranks": [0, 1]}
+
+
+@pytest.mark.skipif(__import__("torch").cuda.device_count() >= 2, reason="needs a box with fewer than 2 GPUs")
+def test_bench_fails_loudly_when_gpus_are_missing(tmp_path):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"],
+                         capture_output=True, text=True, timeout=120, cwd=str(tmp_path),
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert out.returncode == 3, out.stdout + out.stderr
+    assert "needs 2 visible GPUs" in out.stderr and not out.stdout.strip()
 
 
 def test_config_surface_matches_reference_yaml_keys():

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- python3 $R/bench.py --no-cpu-baseline --steps 5 --warmup 1 > $R/gpurun_out/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$c -- python3 $R/bench.py --no-cpu-baseline --no-extras --blocks 1 --steps 5 --warmup 1 > $R/gpurun_out/pmc_$c.log 2>&1
   f=$(find $R/gpurun_out/pmc_$c -name "*counter_collection.csv" | head -1)
   echo "== $c ($f)"
   python3 - "$f" "$c" <<'PY'
