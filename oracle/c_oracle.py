@@ -20,7 +20,7 @@ HIDDEN = 32
 
 def build(force=False):
     """Compile the C restatement with the recipe in oracle/Makefile."""
-    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ses_oracle.c", "ses_oracle_math.h", "ses_tanh_table.h"))
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in os.listdir(_HERE) if f.endswith((".c", ".cpp", ".h")))
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m:
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _SO
@@ -158,7 +158,8 @@ def rollout_spread(theta, init, E, n_agents, max_cycles=25):
 
 
 def rollout_lander(theta, init, E, max_step=300, *, gru=True, obs_mask=0b101100):
-    """LunarLander-lite population rollout.  Returns (fitness[N], ep_return[N,E] f64, ep_steps[N,E])."""
+    """LunarLanderContinuous-v2 population rollout (ses_lander_env.h over the Box2D-style world of ses_b2.h).
+    Returns (fitness[N], ep_return[N,E] f64, ep_steps[N,E])."""
     theta = np.atleast_2d(_f32(theta))
     N = theta.shape[0]
     init = _f32(init)
@@ -174,11 +175,19 @@ def rollout_lander(theta, init, E, max_step=300, *, gru=True, obs_mask=0b101100)
 
 
 class LanderSim:
-    """one LunarLander-lite env driven step by step (used by oracle/lander_env.py)"""
+    """one LunarLanderContinuous-v2 env driven step by step (used by oracle/lander_env.py)"""
 
     def __init__(self):
         self._buf = ctypes.create_string_buffer(lib().o_lander_state_size())
         lib().o_lander_step.restype = ctypes.c_float
+
+    def debug(self):
+        """bodies[3,6] = (cx, cy, angle, vx, vy, omega) of hull / leg -1 / leg +1 and a dict of solver facts"""
+        bodies = np.empty((3, 6), dtype=np.float32)
+        ints = np.zeros(8, dtype=np.int32)
+        lib().o_lander_debug(self._buf, _p(bodies), _p(ints))
+        keys = ("unused", "limit0", "limit1", "game_over", "awake", "leg0", "leg1", "contact_points")
+        return bodies, dict(zip(keys, ints.tolist()))
 
     def reset(self, u16):
         u16 = _f32(u16)

@@ -1,14 +1,16 @@
-"""CPU LunarLander-lite env object speaking the reference's GymWrapper protocol (envs/gym_wrapper.py:23-48)
+"""CPU LunarLanderContinuous-v2 env object speaking the reference's GymWrapper protocol (envs/gym_wrapper.py:23-48)
 with the LunarLanderPOMDP mask (obs[2] = obs[3] = obs[5] = 0, gym_wrapper.py:57-66).  TEST INFRASTRUCTURE.
 
-Physics: oracle/ses_oracle.c::ll_step -- a REDUCED rigid-body model with gym's constants (Box2D is absent:
-parity unpinned, see the C header comment).  Initial states: rows of 16 uniforms replayed round-robin."""
+Physics: oracle/ses_lander_env.h over the Box2D-style world of oracle/ses_b2.h (three bodies, two revolute joints,
+polygon / terrain-edge contacts, 180 + 60 solver iterations per step).  gym and Box2D are absent from the reference tree
+and from this image: parity with them is unpinned, see the headers.  Initial states: rows of 16 uniforms replayed
+round-robin."""
 import numpy as np
 
 from . import c_oracle
 
 
-class LunarLanderLiteEnv:
+class LunarLanderEnv:
     name = "LunarLanderContinuous-v2"
 
     def __init__(self, init_states, max_step=300, pomdp=True):

@@ -1,0 +1,824 @@
+// ses_b2.h -- a small rigid-body world in the manner of Box2D 2.3.0 (the engine behind gym's Box2D envs, reached
+// by the reference through envs/gym_wrapper.py:9,36 for LunarLanderContinuous-v2 / BipedalWalker-v3).
+//
+// THIS FILE EXISTS TWICE, BYTE-IDENTICAL (tests/test_oracle_lander.py checks it): oracle/ses_b2.h is test
+// infrastructure, compiled for the host by oracle/ses_b2_oracle.cpp; simple-es_amd/csrc/ses_b2.h is the product,
+// compiled for gfx950 by csrc/ses_lander.h.  The including file supplies the B2_* macros (function qualifiers, sincos,
+// sqrt).  One text, so that every float operation happens in the same order on both sides and the GPU
+// rollouts can be compared with the CPU's bit for bit; what the comparison then pins is the device build (LDS terrain,
+// wave-level control flow, the compiler), the physics itself is covered by the behavioural tests.
+//
+// Box2D itself is third-party, absent from the reference tree and from this image: PARITY WITH BOX2D IS UNPINNED.
+// What is restated, from the published Box2D 2.3.0 algorithms (file / function names in the comments below):
+//   * bodies with mass, inertia and local centre from b2PolygonShape::ComputeMass (tables: ses_b2_shapes.h);
+//   * b2World::Step = Collide (b2CollideEdgeAndPolygon manifolds against the terrain edges, contact ids, warm-start
+//     impulse matching, begin / end events) + b2Island::Solve (integrate velocities, b2ContactSolver with friction,
+//     two-point block solver and restitution 0, b2RevoluteJoint with limit + motor, warm starting, N velocity
+//     iterations, position integration with the translation / rotation caps, up to M position iterations with
+//     Box2D's own early exit, island sleep timer);
+//   * float32 throughout, no fused multiply-add (Box2D is built without contraction), IEEE division and sqrt.
+// Not restated (documented deviations): continuous collision (b2World::SolveTOI), the broad phase (every terrain edge
+// whose x-range the fattened polygon AABB overlaps is a candidate -- same touching set), Box2D's island traversal
+// order (here: joints in definition order, then contacts by body, then by manifold slot), sinf / cosf of the C
+// library (here: the build's deterministic sincos).
+//
+// All N velocity iterations are run, as in Box2D: with the light legs on the heavy hull the joint rows converge by
+// about 3 % per iteration (measured), a fixed point is not reached earlier.  Quantities that Box2D recomputes in every
+// iteration from values that do not change during a step (the inverse of the joint's 3x3 mass matrix) are computed once
+// per step and applied as a matrix-vector product.
+#pragma once
+#include <stdint.h>
+
+#ifndef B2_FN
+#error "include through ses_b2_oracle.cpp (host) or csrc/ses_lander.h (device): they define the B2_* macros"
+#endif
+
+#include "ses_b2_shapes.h"
+
+namespace b2l {
+
+// ---- b2Settings.h ----
+constexpr float PI = 3.14159265359f;
+constexpr float LINEAR_SLOP = 0.005f;
+constexpr float ANGULAR_SLOP = 2.0f / 180.0f * PI;
+constexpr float POLY_RADIUS = 2.0f * LINEAR_SLOP;
+constexpr float MAX_LINEAR_CORRECTION = 0.2f;
+constexpr float MAX_ANGULAR_CORRECTION = 8.0f / 180.0f * PI;
+constexpr float MAX_TRANSLATION = 2.0f;
+constexpr float MAX_TRANSLATION_SQ = MAX_TRANSLATION * MAX_TRANSLATION;
+constexpr float MAX_ROTATION = 0.5f * PI;
+constexpr float MAX_ROTATION_SQ = MAX_ROTATION * MAX_ROTATION;
+constexpr float BAUMGARTE = 0.2f;
+constexpr float TIME_TO_SLEEP = 0.5f;
+constexpr float LINEAR_SLEEP_TOL = 0.01f;
+constexpr float ANGULAR_SLEEP_TOL = 2.0f / 180.0f * PI;
+constexpr float AABB_EXTENSION = 0.1f;
+constexpr float FLT_BIG = 3.402823466e+38f;
+
+B2_FN float b2min(float a, float b) { return a < b ? a : b; }
+B2_FN float b2max(float a, float b) { return a > b ? a : b; }
+B2_FN float b2clamp(float a, float lo, float hi) { return b2max(lo, b2min(a, hi)); }
+B2_FN float b2abs(float a) { return a > 0.0f ? a : -a; }
+
+struct JointDef {
+    int a, b;                        // body indices
+    float lax, lay, lbx, lby;        // local anchors
+    float lower, upper;              // limits (enableLimit = true), referenceAngle = 0
+};
+
+struct Body {
+    float cx, cy, a;                 // b2Sweep::c, a
+    float vx, vy, w;
+};
+
+struct Xf {                          // b2Transform of a body: q = (s, c), p
+    float s, c, px, py;
+};
+
+constexpr int LIMIT_INACTIVE = 0, LIMIT_LOWER = 1, LIMIT_UPPER = 2, LIMIT_EQUAL = 3;
+
+struct Joint {                       // b2RevoluteJoint, the part that lives across steps
+    float ix, iy, iz, im;            // m_impulse, m_motorImpulse (warm starting)
+    int state;
+    float motor_speed, max_torque;
+};
+
+struct JointTmp {                    // InitVelocityConstraints results, alive for one step
+    float rax, ray, rbx, rby;
+    float ezx, ezy;                  // m_mass.ez.x, .ez.y (the limit-release right-hand side)
+    float i00, i01, i02, i11, i12, i22;   // inverse of the symmetric 3x3 m_mass
+    float j00, j01, j11;             // inverse of its upper-left 2x2 block
+    float motor_mass;
+};
+
+struct Manifold {                    // b2Manifold of (terrain edge `edge`, this body's polygon) + solver temporaries
+    int edge;                        // -1: the slot is empty
+    int count;                       // pointCount; > 0 = touching
+    int type;                        // 0 = e_faceA (the edge is the reference face), 1 = e_faceB
+    float lnx, lny, lpx, lpy;        // localNormal, localPoint
+    float px[2], py[2];              // points[i].localPoint
+    uint32_t id[2];                  // b2ContactID::key
+    float ni[2], ti[2];              // normalImpulse, tangentImpulse
+};
+
+struct ContactTmp {                  // b2ContactVelocityConstraint, alive for one step
+    int vcount;                      // pointCount after the block solver's condition test
+    float nx, ny;
+    float rbx[2], rby[2], nmass[2], tmass[2];
+    float k11, k12, k22, b11, b12, b21, b22;   // K and normalMass (= K^-1): b11 = ex.x, b12 = ey.x, b21 = ex.y, b22 = ey.y
+};
+
+// World description: D provides
+//   static constexpr int NB, NJ, NSLOT (power of two), FIRST_SOLVED (bodies >= this have their contacts solved; body 0 =
+//   hull: touching the terrain ends the episode), VEL_ITERS, POS_ITERS
+//   static const Poly *poly(); static const BodyDef *body(); static const JointDef *joint();
+template <class D>
+struct World {
+    Body body[D::NB];
+    Xf xf[D::NB];                    // transforms at the start of the current step (Collide / solver initialisation)
+    Joint joint[D::NJ];
+    Manifold mf[D::NB][D::NSLOT];
+    float sleep_time[D::NB];
+    bool ground_contact[D::NB];
+    bool game_over, awake, first_step;
+    float fx, fy;                    // b2Body::m_force of body 0 (ApplyForceToCenter), cleared after a step
+};
+
+B2_FN void xf_of(const Body &b, const BodyDef &d, Xf &x)
+{
+    float s, c;
+    B2_SINCOS(b.a, s, c);
+    x.s = s; x.c = c;
+    x.px = b.cx - (c * d.lcx - s * d.lcy);
+    x.py = b.cy - (s * d.lcx + c * d.lcy);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// b2CollideEdgeAndPolygon (b2CollideEdge.cpp, b2EPCollider::Collide) for an edge without adjacent vertices, the edge
+// in world coordinates (the terrain body sits at the origin with angle 0: its transform is the identity, so
+// "frame A" = world and m_xf = xfB).
+struct ClipVertex {
+    float x, y;
+    uint32_t id;
+};
+B2_FN uint32_t contact_id(int indexA, int indexB, int typeA, int typeB)
+{
+    return (uint32_t)indexA | ((uint32_t)indexB << 8) | ((uint32_t)typeA << 16) | ((uint32_t)typeB << 24);
+}
+constexpr int CF_VERTEX = 0, CF_FACE = 1;
+
+B2_FN int clip_segment_to_line(ClipVertex (&out)[2], const ClipVertex (&in)[2], float nx, float ny, float offset, int vertexIndexA)
+{
+    const float d0 = (nx * in[0].x + ny * in[0].y) - offset;
+    const float d1 = (nx * in[1].x + ny * in[1].y) - offset;
+    const bool in0 = d0 <= 0.0f, in1 = d1 <= 0.0f;
+    out[0] = in0 ? in[0] : in[1];                  // vOut[numOut++] = vIn[0] / vIn[1] for the points behind the plane
+    out[1] = in[1];
+    int num = (in0 ? 1 : 0) + (in1 ? 1 : 0);
+    if (d0 * d1 < 0.0f) {                          // exactly one point is behind the plane: num is 1 here
+        const float interp = d0 / (d0 - d1);
+        out[1].x = in[0].x + interp * (in[1].x - in[0].x);
+        out[1].y = in[0].y + interp * (in[1].y - in[0].y);
+        out[1].id = contact_id(vertexIndexA, (int)((in[0].id >> 8) & 0xffu), CF_VERTEX, CF_FACE);
+        num = 2;
+    }
+    return num;
+}
+
+template <int MAXV>
+B2_FN float pick(const float (&arr)[MAXV], int n, int idx)
+{
+    float r = arr[0];
+    B2_UNROLL
+    for (int i = 1; i < MAXV; ++i) r = (i < n && i == idx) ? arr[i] : r;
+    return r;
+}
+
+// polygon in world coordinates: vertices (wx, wy), normals (wnx, wny), centroid (ccx, ccy); the body transform xf and
+// the local polygon are needed for the manifold's local points.  Fills the geometric part of `m` (count, type,
+// local normal / point, points, ids); impulses are left to the caller.
+B2_FN void collide_edge_polygon(const Poly &P, const Xf &xf, const float (&wx)[6], const float (&wy)[6],
+                                const float (&wnx)[6], const float (&wny)[6], float ccx, float ccy,
+                                float v1x, float v1y, float v2x, float v2y, Manifold &m)
+{
+    m.count = 0;
+    const int n = P.n;
+    float e1x = v2x - v1x, e1y = v2y - v1y;
+    {
+        const float len = B2_SQRT(e1x * e1x + e1y * e1y);       // b2Vec2::Normalize
+        if (!(len < 1.1920928955078125e-7f)) {
+            const float inv = 1.0f / len;
+            e1x *= inv; e1y *= inv;
+        }
+    }
+    const float n1x = e1y, n1y = -e1x;                            // m_normal1
+    const float offset1 = n1x * (ccx - v1x) + n1y * (ccy - v1y);
+    const bool front = offset1 >= 0.0f;
+    const float mnx = front ? n1x : -n1x, mny = front ? n1y : -n1y;           // m_normal
+    const float limx = front ? -n1x : n1x, limy = front ? -n1y : n1y;          // m_lowerLimit = m_upperLimit
+    const float radius = 2.0f * POLY_RADIUS;
+
+    // ComputeEdgeSeparation
+    float edge_sep = FLT_BIG;
+    B2_UNROLL
+    for (int i = 0; i < 6; ++i) {
+        if (i < n) {
+            const float s = mnx * (wx[i] - v1x) + mny * (wy[i] - v1y);
+            if (s < edge_sep) edge_sep = s;
+        }
+    }
+    if (edge_sep > radius) return;
+
+    // ComputePolygonSeparation
+    int poly_index = -1;
+    float poly_sep = -FLT_BIG;
+    bool poly_early = false;
+    const float perpx = -mny, perpy = mnx;
+    B2_UNROLL
+    for (int i = 0; i < 6; ++i) {
+        if (i < n && !poly_early) {
+            const float nx = -wnx[i], ny = -wny[i];
+            const float s1 = nx * (wx[i] - v1x) + ny * (wy[i] - v1y);
+            const float s2 = nx * (wx[i] - v2x) + ny * (wy[i] - v2y);
+            const float s = b2min(s1, s2);
+            if (s > radius) {
+                poly_index = i; poly_sep = s; poly_early = true;
+            } else {
+                // adjacency: both branches compare against the same limit for an isolated edge
+                const bool skip = ((nx - limx) * mnx + (ny - limy) * mny) < -ANGULAR_SLOP;
+                (void)perpx; (void)perpy;
+                if (!skip && s > poly_sep) { poly_index = i; poly_sep = s; }
+            }
+        }
+    }
+    if (poly_index >= 0 && poly_sep > radius) return;
+
+    const float k_relativeTol = 0.98f, k_absoluteTol = 0.001f;
+    const bool primary_edge = poly_index < 0 || !(poly_sep > k_relativeTol * edge_sep + k_absoluteTol);
+
+    ClipVertex ie[2];
+    int rf_i1, rf_i2;
+    float rf_v1x, rf_v1y, rf_v2x, rf_v2y, rf_nx, rf_ny;
+    if (primary_edge) {
+        m.type = 0;
+        int best = 0;
+        float best_value = mnx * wnx[0] + mny * wny[0];
+        B2_UNROLL
+        for (int i = 1; i < 6; ++i) {
+            if (i < n) {
+                const float value = mnx * wnx[i] + mny * wny[i];
+                if (value < best_value) { best_value = value; best = i; }
+            }
+        }
+        const int i1 = best, i2 = i1 + 1 < n ? i1 + 1 : 0;
+        ie[0].x = pick(wx, n, i1); ie[0].y = pick(wy, n, i1); ie[0].id = contact_id(0, i1, CF_FACE, CF_VERTEX);
+        ie[1].x = pick(wx, n, i2); ie[1].y = pick(wy, n, i2); ie[1].id = contact_id(0, i2, CF_FACE, CF_VERTEX);
+        if (front) {
+            rf_i1 = 0; rf_i2 = 1; rf_v1x = v1x; rf_v1y = v1y; rf_v2x = v2x; rf_v2y = v2y; rf_nx = n1x; rf_ny = n1y;
+        } else {
+            rf_i1 = 1; rf_i2 = 0; rf_v1x = v2x; rf_v1y = v2y; rf_v2x = v1x; rf_v2y = v1y; rf_nx = -n1x; rf_ny = -n1y;
+        }
+    } else {
+        m.type = 1;
+        ie[0].x = v1x; ie[0].y = v1y; ie[0].id = contact_id(0, poly_index, CF_VERTEX, CF_FACE);
+        ie[1].x = v2x; ie[1].y = v2y; ie[1].id = contact_id(0, poly_index, CF_VERTEX, CF_FACE);
+        rf_i1 = poly_index; rf_i2 = rf_i1 + 1 < n ? rf_i1 + 1 : 0;
+        rf_v1x = pick(wx, n, rf_i1); rf_v1y = pick(wy, n, rf_i1);
+        rf_v2x = pick(wx, n, rf_i2); rf_v2y = pick(wy, n, rf_i2);
+        rf_nx = pick(wnx, n, rf_i1); rf_ny = pick(wny, n, rf_i1);
+    }
+    const float sn1x = rf_ny, sn1y = -rf_nx, sn2x = -sn1x, sn2y = -sn1y;
+    const float so1 = sn1x * rf_v1x + sn1y * rf_v1y;
+    const float so2 = sn2x * rf_v2x + sn2y * rf_v2y;
+    ClipVertex c1[2], c2[2];
+    if (clip_segment_to_line(c1, ie, sn1x, sn1y, so1, rf_i1) < 2) return;
+    if (clip_segment_to_line(c2, c1, sn2x, sn2y, so2, rf_i2) < 2) return;
+
+    if (primary_edge) {
+        m.lnx = rf_nx; m.lny = rf_ny; m.lpx = rf_v1x; m.lpy = rf_v1y;
+    } else {
+        m.lnx = pick(P.nx, n, rf_i1); m.lny = pick(P.ny, n, rf_i1);
+        m.lpx = pick(P.vx, n, rf_i1); m.lpy = pick(P.vy, n, rf_i1);
+    }
+    int count = 0;
+    B2_UNROLL
+    for (int i = 0; i < 2; ++i) {
+        const float sep = rf_nx * (c2[i].x - rf_v1x) + rf_ny * (c2[i].y - rf_v1y);
+        if (sep <= radius) {
+            float lx, ly;
+            uint32_t id;
+            if (primary_edge) {                                   // b2MulT(m_xf, v)
+                const float dx = c2[i].x - xf.px, dy = c2[i].y - xf.py;
+                lx = xf.c * dx + xf.s * dy;
+                ly = -xf.s * dx + xf.c * dy;
+                id = c2[i].id;
+            } else {
+                lx = c2[i].x; ly = c2[i].y;
+                const uint32_t k = c2[i].id;                      // swap the A and B features
+                id = ((k >> 8) & 0xffu) | ((k & 0xffu) << 8) | (((k >> 24) & 0xffu) << 16) | (((k >> 16) & 0xffu) << 24);
+            }
+            if (count == 0) { m.px[0] = lx; m.py[0] = ly; m.id[0] = id; }
+            else { m.px[1] = lx; m.py[1] = ly; m.id[1] = id; }
+            ++count;
+        }
+    }
+    m.count = count;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// b2World::Step, first half: b2ContactManager::Collide over the (terrain edge, body polygon) pairs.
+// T: terrain with  int n_edges() const;  int index_of(float x) const  (edge containing x, unclamped);
+//                  void edge(int k, float &x1, float &y1, float &x2, float &y2) const.
+template <class D, class T>
+B2_FN void collide(World<D> &w, const T &terr)
+{
+    B2_UNROLL
+    for (int b = 0; b < D::NB; ++b) {
+        const Poly &P = D::poly()[b];
+        const BodyDef &bd = D::body()[b];
+        xf_of(w.body[b], bd, w.xf[b]);
+        const Xf &xf = w.xf[b];
+        float wx[6], wy[6], wnx[6], wny[6];
+        float xmin = FLT_BIG, xmax = -FLT_BIG, ymin = FLT_BIG;
+        B2_UNROLL
+        for (int i = 0; i < 6; ++i) {
+            if (i < P.n) {
+                wx[i] = (xf.c * P.vx[i] - xf.s * P.vy[i]) + xf.px;
+                wy[i] = (xf.s * P.vx[i] + xf.c * P.vy[i]) + xf.py;
+                wnx[i] = xf.c * P.nx[i] - xf.s * P.ny[i];
+                wny[i] = xf.s * P.nx[i] + xf.c * P.ny[i];
+                xmin = b2min(xmin, wx[i]); xmax = b2max(xmax, wx[i]); ymin = b2min(ymin, wy[i]);
+            } else {
+                wx[i] = 0.0f; wy[i] = 0.0f; wnx[i] = 0.0f; wny[i] = 0.0f;
+            }
+        }
+        const float ccx = (xf.c * P.cx - xf.s * P.cy) + xf.px, ccy = (xf.s * P.cx + xf.c * P.cy) + xf.py;
+        int k_lo = terr.index_of(xmin - AABB_EXTENSION), k_hi = terr.index_of(xmax + AABB_EXTENSION);
+        k_lo = k_lo < 0 ? 0 : k_lo;
+        k_hi = k_hi > terr.n_edges() - 1 ? terr.n_edges() - 1 : k_hi;
+        k_hi = k_hi > k_lo + D::NSLOT - 1 ? k_lo + D::NSLOT - 1 : k_hi;
+        B2_UNROLL
+        for (int s = 0; s < D::NSLOT; ++s) {
+            Manifold &m = w.mf[b][s];
+            const int k = k_lo + ((s - k_lo) & (D::NSLOT - 1));       // the candidate edge that maps to this slot
+            const bool candidate = k <= k_hi && k_lo <= k_hi;
+            const bool was_touching = m.edge >= 0 && m.count > 0;
+            const bool same_edge = candidate && m.edge == k;
+            Manifold old = m;
+            m.count = 0;
+            m.edge = candidate ? k : -1;
+            if (candidate) {
+                float x1, y1, x2, y2;
+                terr.edge(k, x1, y1, x2, y2);
+                // (the manifold function returns no points for anything farther than 2 * polygonRadius; this test
+                //  only skips its evaluation for a polygon that is clearly above the edge)
+                if (!(ymin - AABB_EXTENSION > b2max(y1, y2)))
+                    collide_edge_polygon(P, xf, wx, wy, wnx, wny, ccx, ccy, x1, y1, x2, y2, m);
+            }
+            // b2Contact::Update: impulses of the points whose ids persist
+            B2_UNROLL
+            for (int i = 0; i < 2; ++i) {
+                m.ni[i] = 0.0f; m.ti[i] = 0.0f;
+                if (same_edge && i < m.count) {
+                    B2_UNROLL
+                    for (int j = 0; j < 2; ++j) {
+                        if (j < old.count && old.id[j] == m.id[i]) { m.ni[i] = old.ni[j]; m.ti[i] = old.ti[j]; break; }
+                    }
+                }
+            }
+            const bool still = same_edge && was_touching;
+            if (was_touching && !(still && m.count > 0)) w.ground_contact[b] = false;          // EndContact
+            if (m.count > 0 && !still) {                                                       // BeginContact
+                w.ground_contact[b] = true;
+                if (b < D::FIRST_SOLVED) w.game_over = true;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// b2RevoluteJoint
+template <class D>
+B2_FN void joint_init(World<D> &w, int j, JointTmp &t)
+{
+    const JointDef &jd = D::joint()[j];
+    Joint &J = w.joint[j];
+    const BodyDef &da = D::body()[jd.a], &db = D::body()[jd.b];
+    const Xf &qa = w.xf[jd.a], &qb = w.xf[jd.b];
+    Body &A = w.body[jd.a], &B = w.body[jd.b];
+    {
+        const float ax = jd.lax - da.lcx, ay = jd.lay - da.lcy, bx = jd.lbx - db.lcx, by = jd.lby - db.lcy;
+        t.rax = qa.c * ax - qa.s * ay; t.ray = qa.s * ax + qa.c * ay;
+        t.rbx = qb.c * bx - qb.s * by; t.rby = qb.s * bx + qb.c * by;
+    }
+    const float mA = da.inv_mass, mB = db.inv_mass, iA = da.inv_i, iB = db.inv_i;
+    // m_mass (symmetric): ex = (exx, eyx, ezx), ey = (eyx, eyy, ezy), ez = (ezx, ezy, ezz)
+    const float exx = mA + mB + t.ray * t.ray * iA + t.rby * t.rby * iB;
+    const float eyx = -t.ray * t.rax * iA - t.rby * t.rbx * iB;
+    const float ezx = -t.ray * iA - t.rby * iB;
+    const float eyy = mA + mB + t.rax * t.rax * iA + t.rbx * t.rbx * iB;
+    const float ezy = t.rax * iA + t.rbx * iB;
+    const float ezz = iA + iB;
+    t.ezx = ezx; t.ezy = ezy;
+    {   // inverse by cofactors (b2Mat33::Solve33 divides by the same determinant)
+        const float c00 = eyy * ezz - ezy * ezy, c01 = ezy * ezx - eyx * ezz, c02 = eyx * ezy - eyy * ezx;
+        float det = exx * c00 + eyx * c01 + ezx * c02;
+        if (det != 0.0f) det = 1.0f / det;
+        const float c11 = exx * ezz - ezx * ezx, c12 = eyx * ezx - exx * ezy, c22 = exx * eyy - eyx * eyx;
+        t.i00 = det * c00; t.i01 = det * c01; t.i02 = det * c02; t.i11 = det * c11; t.i12 = det * c12; t.i22 = det * c22;
+        float d2 = exx * eyy - eyx * eyx;                    // b2Mat33::Solve22
+        if (d2 != 0.0f) d2 = 1.0f / d2;
+        t.j00 = d2 * eyy; t.j01 = -d2 * eyx; t.j11 = d2 * exx;
+    }
+    t.motor_mass = iA + iB;
+    if (t.motor_mass > 0.0f) t.motor_mass = 1.0f / t.motor_mass;
+    {
+        const float angle = B.a - A.a;                       // referenceAngle = 0
+        if (b2abs(jd.upper - jd.lower) < 2.0f * ANGULAR_SLOP) {
+            J.state = LIMIT_EQUAL;
+        } else if (angle <= jd.lower) {
+            if (J.state != LIMIT_LOWER) J.iz = 0.0f;
+            J.state = LIMIT_LOWER;
+        } else if (angle >= jd.upper) {
+            if (J.state != LIMIT_UPPER) J.iz = 0.0f;
+            J.state = LIMIT_UPPER;
+        } else {
+            J.state = LIMIT_INACTIVE;
+            J.iz = 0.0f;
+        }
+    }
+    // warm start (dtRatio = 1 for a constant time step: 50.0f * 0.02f rounds to 1.0f)
+    const float Px = J.ix, Py = J.iy;
+    A.vx -= mA * Px; A.vy -= mA * Py;
+    A.w -= iA * ((t.rax * Py - t.ray * Px) + J.im + J.iz);
+    B.vx += mB * Px; B.vy += mB * Py;
+    B.w += iB * ((t.rbx * Py - t.rby * Px) + J.im + J.iz);
+}
+
+template <class D>
+B2_FN void joint_solve_velocity(World<D> &w, int j, const JointTmp &t, float dt)
+{
+    const JointDef &jd = D::joint()[j];
+    Joint &J = w.joint[j];
+    const BodyDef &da = D::body()[jd.a], &db = D::body()[jd.b];
+    Body &A = w.body[jd.a], &B = w.body[jd.b];
+    const float mA = da.inv_mass, mB = db.inv_mass, iA = da.inv_i, iB = db.inv_i;
+    if (J.state != LIMIT_EQUAL) {                             // motor (enableMotor = true)
+        const float Cdot = B.w - A.w - J.motor_speed;
+        float impulse = -t.motor_mass * Cdot;
+        const float old = J.im;
+        const float max_impulse = dt * J.max_torque;
+        J.im = b2clamp(old + impulse, -max_impulse, max_impulse);
+        impulse = J.im - old;
+        A.w -= iA * impulse;
+        B.w += iB * impulse;
+    }
+    const float c1x = (B.vx - B.w * t.rby) - (A.vx - A.w * t.ray);
+    const float c1y = (B.vy + B.w * t.rbx) - (A.vy + A.w * t.rax);
+    float ix, iy, iz = 0.0f;
+    if (J.state != LIMIT_INACTIVE) {
+        const float c2 = B.w - A.w;
+        ix = -(t.i00 * c1x + t.i01 * c1y + t.i02 * c2);
+        iy = -(t.i01 * c1x + t.i11 * c1y + t.i12 * c2);
+        iz = -(t.i02 * c1x + t.i12 * c1y + t.i22 * c2);
+        if (J.state != LIMIT_EQUAL) {
+            const float new_impulse = J.iz + iz;
+            const bool release = J.state == LIMIT_LOWER ? new_impulse < 0.0f : new_impulse > 0.0f;
+            if (release) {                                     // the limit lets go: solve the point rows alone
+                const float rx = -c1x + J.iz * t.ezx, ry = -c1y + J.iz * t.ezy;
+                ix = t.j00 * rx + t.j01 * ry;
+                iy = t.j01 * rx + t.j11 * ry;
+                iz = -J.iz;
+            }
+        }
+    } else {
+        ix = -(t.j00 * c1x + t.j01 * c1y);
+        iy = -(t.j01 * c1x + t.j11 * c1y);
+    }
+    J.ix += ix; J.iy += iy; J.iz += iz;
+    A.vx -= mA * ix; A.vy -= mA * iy;
+    A.w -= iA * ((t.rax * iy - t.ray * ix) + iz);
+    B.vx += mB * ix; B.vy += mB * iy;
+    B.w += iB * ((t.rbx * iy - t.rby * ix) + iz);
+}
+
+template <class D>
+B2_FN bool joint_solve_position(World<D> &w, int j)
+{
+    const JointDef &jd = D::joint()[j];
+    const Joint &J = w.joint[j];
+    const BodyDef &da = D::body()[jd.a], &db = D::body()[jd.b];
+    Body &A = w.body[jd.a], &B = w.body[jd.b];
+    const float mA = da.inv_mass, mB = db.inv_mass, iA = da.inv_i, iB = db.inv_i;
+    float motor_mass = iA + iB;
+    if (motor_mass > 0.0f) motor_mass = 1.0f / motor_mass;
+    float angular_error = 0.0f;
+    if (J.state != LIMIT_INACTIVE) {
+        const float angle = B.a - A.a;
+        float limit_impulse = 0.0f;
+        if (J.state == LIMIT_EQUAL) {
+            const float C = b2clamp(angle - jd.lower, -MAX_ANGULAR_CORRECTION, MAX_ANGULAR_CORRECTION);
+            limit_impulse = -motor_mass * C;
+            angular_error = b2abs(C);
+        } else if (J.state == LIMIT_LOWER) {
+            float C = angle - jd.lower;
+            angular_error = -C;
+            C = b2clamp(C + ANGULAR_SLOP, -MAX_ANGULAR_CORRECTION, 0.0f);
+            limit_impulse = -motor_mass * C;
+        } else {
+            float C = angle - jd.upper;
+            angular_error = C;
+            C = b2clamp(C - ANGULAR_SLOP, 0.0f, MAX_ANGULAR_CORRECTION);
+            limit_impulse = -motor_mass * C;
+        }
+        A.a -= iA * limit_impulse;
+        B.a += iB * limit_impulse;
+    }
+    float sa, ca, sb, cb;
+    B2_SINCOS(A.a, sa, ca);
+    B2_SINCOS(B.a, sb, cb);
+    const float ax = jd.lax - da.lcx, ay = jd.lay - da.lcy, bx = jd.lbx - db.lcx, by = jd.lby - db.lcy;
+    const float rax = ca * ax - sa * ay, ray = sa * ax + ca * ay;
+    const float rbx = cb * bx - sb * by, rby = sb * bx + cb * by;
+    const float Cx = B.cx + rbx - A.cx - rax, Cy = B.cy + rby - A.cy - ray;
+    const float position_error = B2_SQRT(Cx * Cx + Cy * Cy);
+    const float k11 = mA + mB + iA * ray * ray + iB * rby * rby;
+    const float k12 = -iA * rax * ray - iB * rbx * rby;
+    const float k22 = mA + mB + iA * rax * rax + iB * rbx * rbx;
+    float det = k11 * k22 - k12 * k12;
+    if (det != 0.0f) det = 1.0f / det;
+    const float ix = -(det * (k22 * Cx - k12 * Cy)), iy = -(det * (k11 * Cy - k12 * Cx));
+    A.cx -= mA * ix; A.cy -= mA * iy;
+    A.a -= iA * (rax * iy - ray * ix);
+    B.cx += mB * ix; B.cy += mB * iy;
+    B.a += iB * (rbx * iy - rby * ix);
+    return position_error <= LINEAR_SLOP && angular_error <= ANGULAR_SLOP;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// b2ContactSolver for (static terrain at the identity transform = body A, dynamic polygon body = body B): every
+// A-side term is a product with invMassA = invIA = 0 or a difference with vA = wA = 0 and drops out exactly.
+B2_FN void contact_init(const Manifold &m, ContactTmp &t, const Body &B, const BodyDef &bd, const Xf &xf)
+{
+    t.vcount = m.count;
+    if (m.count == 0) return;
+    const float mB = bd.inv_mass, iB = bd.inv_i;
+    float nx, ny;
+    float ptx[2], pty[2];
+    if (m.type == 0) {                                        // b2WorldManifold::Initialize, e_faceA
+        nx = m.lnx; ny = m.lny;
+        B2_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            const float cpx = (xf.c * m.px[i] - xf.s * m.py[i]) + xf.px, cpy = (xf.s * m.px[i] + xf.c * m.py[i]) + xf.py;
+            const float d = POLY_RADIUS - ((cpx - m.lpx) * nx + (cpy - m.lpy) * ny);
+            const float cAx = cpx + d * nx, cAy = cpy + d * ny;
+            const float cBx = cpx - POLY_RADIUS * nx, cBy = cpy - POLY_RADIUS * ny;
+            ptx[i] = 0.5f * (cAx + cBx); pty[i] = 0.5f * (cAy + cBy);
+        }
+    } else {                                                  // e_faceB
+        nx = xf.c * m.lnx - xf.s * m.lny; ny = xf.s * m.lnx + xf.c * m.lny;
+        const float ppx = (xf.c * m.lpx - xf.s * m.lpy) + xf.px, ppy = (xf.s * m.lpx + xf.c * m.lpy) + xf.py;
+        B2_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            const float cpx = m.px[i], cpy = m.py[i];
+            const float d = POLY_RADIUS - ((cpx - ppx) * nx + (cpy - ppy) * ny);
+            const float cBx = cpx + d * nx, cBy = cpy + d * ny;
+            const float cAx = cpx - POLY_RADIUS * nx, cAy = cpy - POLY_RADIUS * ny;
+            ptx[i] = 0.5f * (cAx + cBx); pty[i] = 0.5f * (cAy + cBy);
+        }
+        nx = -nx; ny = -ny;
+    }
+    t.nx = nx; t.ny = ny;
+    const float tx = ny, ty = -nx;                            // b2Cross(normal, 1.0f)
+    float rn[2];
+    B2_UNROLL
+    for (int i = 0; i < 2; ++i) {
+        t.rbx[i] = ptx[i] - B.cx; t.rby[i] = pty[i] - B.cy;
+        rn[i] = t.rbx[i] * ny - t.rby[i] * nx;
+        const float kn = mB + iB * rn[i] * rn[i];
+        t.nmass[i] = kn > 0.0f ? 1.0f / kn : 0.0f;
+        const float rt = t.rbx[i] * ty - t.rby[i] * tx;
+        const float kt = mB + iB * rt * rt;
+        t.tmass[i] = kt > 0.0f ? 1.0f / kt : 0.0f;
+        // restitution 0: velocityBias = 0
+    }
+    t.k11 = 0.0f; t.k12 = 0.0f; t.k22 = 0.0f; t.b11 = 0.0f; t.b12 = 0.0f; t.b21 = 0.0f; t.b22 = 0.0f;
+    if (m.count == 2) {
+        const float k11 = mB + iB * rn[0] * rn[0], k22 = mB + iB * rn[1] * rn[1], k12 = mB + iB * rn[0] * rn[1];
+        if (k11 * k11 < 1000.0f * (k11 * k22 - k12 * k12)) {
+            t.k11 = k11; t.k12 = k12; t.k22 = k22;
+            float det = k11 * k22 - k12 * k12;                // b2Mat22::GetInverse
+            if (det != 0.0f) det = 1.0f / det;
+            t.b11 = det * k22; t.b12 = -det * k12; t.b21 = -det * k12; t.b22 = det * k11;
+        } else {
+            t.vcount = 1;
+        }
+    }
+}
+
+B2_FN void contact_warm_start(const Manifold &m, const ContactTmp &t, Body &B, const BodyDef &bd)
+{
+    const float tx = t.ny, ty = -t.nx;
+    B2_UNROLL
+    for (int i = 0; i < 2; ++i) {
+        if (i < t.vcount) {
+            const float Px = m.ni[i] * t.nx + m.ti[i] * tx, Py = m.ni[i] * t.ny + m.ti[i] * ty;
+            B.w += bd.inv_i * (t.rbx[i] * Py - t.rby[i] * Px);
+            B.vx += bd.inv_mass * Px; B.vy += bd.inv_mass * Py;
+        }
+    }
+}
+
+B2_FN void contact_solve_velocity(Manifold &m, const ContactTmp &t, Body &B, const BodyDef &bd)
+{
+    if (t.vcount == 0) return;
+    const float mB = bd.inv_mass, iB = bd.inv_i, friction = bd.friction;
+    const float nx = t.nx, ny = t.ny, tx = ny, ty = -nx;
+    B2_UNROLL
+    for (int i = 0; i < 2; ++i) {                              // friction first
+        if (i < t.vcount) {
+            const float dvx = B.vx - B.w * t.rby[i], dvy = B.vy + B.w * t.rbx[i];
+            const float vt = dvx * tx + dvy * ty;
+            float lambda = t.tmass[i] * (-vt);
+            const float max_friction = friction * m.ni[i];
+            const float new_impulse = b2clamp(m.ti[i] + lambda, -max_friction, max_friction);
+            lambda = new_impulse - m.ti[i];
+            m.ti[i] = new_impulse;
+            const float Px = lambda * tx, Py = lambda * ty;
+            B.vx += mB * Px; B.vy += mB * Py;
+            B.w += iB * (t.rbx[i] * Py - t.rby[i] * Px);
+        }
+    }
+    if (t.vcount == 1) {
+        const float dvx = B.vx - B.w * t.rby[0], dvy = B.vy + B.w * t.rbx[0];
+        const float vn = dvx * nx + dvy * ny;
+        float lambda = -t.nmass[0] * vn;
+        const float new_impulse = b2max(m.ni[0] + lambda, 0.0f);
+        lambda = new_impulse - m.ni[0];
+        m.ni[0] = new_impulse;
+        const float Px = lambda * nx, Py = lambda * ny;
+        B.vx += mB * Px; B.vy += mB * Py;
+        B.w += iB * (t.rbx[0] * Py - t.rby[0] * Px);
+    } else {                                                   // block solver (b2ContactSolver.cpp, the four cases)
+        const float ax = m.ni[0], ay = m.ni[1];
+        const float dv1x = B.vx - B.w * t.rby[0], dv1y = B.vy + B.w * t.rbx[0];
+        const float dv2x = B.vx - B.w * t.rby[1], dv2y = B.vy + B.w * t.rbx[1];
+        float bx = dv1x * nx + dv1y * ny, by = dv2x * nx + dv2y * ny;
+        bx -= t.k11 * ax + t.k12 * ay;
+        by -= t.k12 * ax + t.k22 * ay;
+        float xx = -(t.b11 * bx + t.b12 * by), xy = -(t.b21 * bx + t.b22 * by);      // case 1
+        bool solved = xx >= 0.0f && xy >= 0.0f;
+        if (!solved) {                                         // case 2
+            xx = -t.nmass[0] * bx; xy = 0.0f;
+            const float vn2 = t.k12 * xx + by;
+            solved = xx >= 0.0f && vn2 >= 0.0f;
+        }
+        if (!solved) {                                         // case 3
+            xx = 0.0f; xy = -t.nmass[1] * by;
+            const float vn1 = t.k12 * xy + bx;
+            solved = xy >= 0.0f && vn1 >= 0.0f;
+        }
+        if (!solved) {                                         // case 4
+            xx = 0.0f; xy = 0.0f;
+            solved = bx >= 0.0f && by >= 0.0f;
+        }
+        if (solved) {
+            const float dx = xx - ax, dy = xy - ay;
+            const float P1x = dx * nx, P1y = dx * ny, P2x = dy * nx, P2y = dy * ny;
+            B.vx += mB * (P1x + P2x); B.vy += mB * (P1y + P2y);
+            B.w += iB * ((t.rbx[0] * P1y - t.rby[0] * P1x) + (t.rbx[1] * P2y - t.rby[1] * P2x));
+            m.ni[0] = xx; m.ni[1] = xy;
+        }
+    }
+}
+
+// b2ContactSolver::SolvePositionConstraints for one manifold; returns its minimum separation
+B2_FN float contact_solve_position(const Manifold &m, Body &B, const BodyDef &bd)
+{
+    float min_separation = 0.0f;
+    const float mB = bd.inv_mass, iB = bd.inv_i;
+    B2_UNROLL
+    for (int i = 0; i < 2; ++i) {
+        if (i < m.count) {
+            float s, c;
+            B2_SINCOS(B.a, s, c);
+            const float px = B.cx - (c * bd.lcx - s * bd.lcy), py = B.cy - (s * bd.lcx + c * bd.lcy);
+            float nx, ny, ptx, pty, separation;
+            if (m.type == 0) {                                // b2PositionSolverManifold, e_faceA
+                nx = m.lnx; ny = m.lny;
+                const float cpx = (c * m.px[i] - s * m.py[i]) + px, cpy = (s * m.px[i] + c * m.py[i]) + py;
+                separation = ((cpx - m.lpx) * nx + (cpy - m.lpy) * ny) - POLY_RADIUS - POLY_RADIUS;
+                ptx = cpx; pty = cpy;
+            } else {
+                nx = c * m.lnx - s * m.lny; ny = s * m.lnx + c * m.lny;
+                const float ppx = (c * m.lpx - s * m.lpy) + px, ppy = (s * m.lpx + c * m.lpy) + py;
+                const float cpx = m.px[i], cpy = m.py[i];
+                separation = ((cpx - ppx) * nx + (cpy - ppy) * ny) - POLY_RADIUS - POLY_RADIUS;
+                ptx = cpx; pty = cpy;
+                nx = -nx; ny = -ny;
+            }
+            const float rbx = ptx - B.cx, rby = pty - B.cy;
+            min_separation = b2min(min_separation, separation);
+            const float C = b2clamp(BAUMGARTE * (separation + LINEAR_SLOP), -MAX_LINEAR_CORRECTION, 0.0f);
+            const float rn = rbx * ny - rby * nx;
+            const float K = mB + iB * rn * rn;
+            const float impulse = K > 0.0f ? -C / K : 0.0f;
+            const float Px = impulse * nx, Py = impulse * ny;
+            B.cx += mB * Px; B.cy += mB * Py;
+            B.a += iB * (rbx * Py - rby * Px);
+        }
+    }
+    return min_separation;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// b2World::Step(dt, D::VEL_ITERS, D::POS_ITERS)
+template <class D, class T>
+B2_FN void world_step(World<D> &w, const T &terr, float dt)
+{
+    collide(w, terr);
+
+    // b2Island::Solve: integrate velocities (gravity, no damping: v *= 1 / (1 + h * 0) is exact)
+    B2_UNROLL
+    for (int b = 0; b < D::NB; ++b) {
+        const BodyDef &bd = D::body()[b];
+        const float fx = b == 0 ? w.fx : 0.0f, fy = b == 0 ? w.fy : 0.0f;
+        w.body[b].vx += dt * (0.0f + bd.inv_mass * fx);
+        w.body[b].vy += dt * (D::GRAVITY_Y + bd.inv_mass * fy);
+    }
+    w.fx = 0.0f; w.fy = 0.0f;
+
+    ContactTmp ct[D::NB - D::FIRST_SOLVED][D::NSLOT];
+    JointTmp jt[D::NJ];
+    bool any_contact = false;
+    B2_UNROLL
+    for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
+        B2_UNROLL
+        for (int s = 0; s < D::NSLOT; ++s) {
+            contact_init(w.mf[b][s], ct[b - D::FIRST_SOLVED][s], w.body[b], D::body()[b], w.xf[b]);
+            any_contact = any_contact || w.mf[b][s].count > 0;
+        }
+    }
+    B2_UNROLL
+    for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
+        B2_UNROLL
+        for (int s = 0; s < D::NSLOT; ++s) contact_warm_start(w.mf[b][s], ct[b - D::FIRST_SOLVED][s], w.body[b], D::body()[b]);
+    }
+    B2_UNROLL
+    for (int j = 0; j < D::NJ; ++j) joint_init(w, j, jt[j]);
+
+    // (no wave-level votes anywhere in this file: a world only ever looks at its own state, so the code may run
+    //  under any divergence; in flight the contact rows are skipped as a whole)
+    for (int it = 0; it < D::VEL_ITERS; ++it) {
+        B2_UNROLL
+        for (int j = 0; j < D::NJ; ++j) joint_solve_velocity(w, j, jt[j], dt);
+        if (any_contact) {
+            B2_UNROLL
+            for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
+                B2_UNROLL
+                for (int s = 0; s < D::NSLOT; ++s)
+                    contact_solve_velocity(w.mf[b][s], ct[b - D::FIRST_SOLVED][s], w.body[b], D::body()[b]);
+            }
+        }
+    }
+
+    // integrate positions
+    B2_UNROLL
+    for (int b = 0; b < D::NB; ++b) {
+        Body &B = w.body[b];
+        const float trx = dt * B.vx, try_ = dt * B.vy;
+        if (trx * trx + try_ * try_ > MAX_TRANSLATION_SQ) {
+            const float ratio = MAX_TRANSLATION / B2_SQRT(trx * trx + try_ * try_);
+            B.vx *= ratio; B.vy *= ratio;
+        }
+        const float rot = dt * B.w;
+        if (rot * rot > MAX_ROTATION_SQ) {
+            const float ratio = MAX_ROTATION / b2abs(rot);
+            B.w *= ratio;
+        }
+        B.cx += dt * B.vx; B.cy += dt * B.vy;
+        B.a += dt * B.w;
+    }
+
+    // position iterations with Box2D's own early exit
+    bool position_solved = false;
+    for (int pit = 0; pit < D::POS_ITERS && !position_solved; ++pit) {
+        {
+            float min_separation = 0.0f;
+            if (any_contact) {
+                B2_UNROLL
+                for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
+                    B2_UNROLL
+                    for (int s = 0; s < D::NSLOT; ++s)
+                        min_separation = b2min(min_separation, contact_solve_position(w.mf[b][s], w.body[b], D::body()[b]));
+                }
+            }
+            const bool contacts_okay = min_separation >= -3.0f * LINEAR_SLOP;
+            bool joints_okay = true;
+            B2_UNROLL
+            for (int j = 0; j < D::NJ; ++j) {
+                const bool ok = joint_solve_position(w, j);
+                joints_okay = joints_okay && ok;
+            }
+            position_solved = contacts_okay && joints_okay;
+        }
+    }
+
+    // sleep (b2Island::Solve, the island = all bodies of the world)
+    float min_sleep = FLT_BIG;
+    B2_UNROLL
+    for (int b = 0; b < D::NB; ++b) {
+        const Body &B = w.body[b];
+        if (B.w * B.w > ANGULAR_SLEEP_TOL * ANGULAR_SLEEP_TOL || B.vx * B.vx + B.vy * B.vy > LINEAR_SLEEP_TOL * LINEAR_SLEEP_TOL) {
+            w.sleep_time[b] = 0.0f;
+            min_sleep = 0.0f;
+        } else {
+            w.sleep_time[b] += dt;
+            min_sleep = b2min(min_sleep, w.sleep_time[b]);
+        }
+    }
+    if (min_sleep >= TIME_TO_SLEEP && position_solved) w.awake = false;
+    w.first_step = false;
+}
+
+}  // namespace b2l

@@ -1,0 +1,98 @@
+// ses_b2_oracle.cpp -- TEST INFRASTRUCTURE (oracle).  Host build of the Box2D-style world (ses_b2.h) and of the gym
+// Box2D envs on top of it (ses_lander_env.h), with C entry points for ses_oracle.c's population rollouts and for
+// the Python env objects (oracle/lander_env.py).  See those headers for what is restated and what is not pinned.
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+extern "C" {
+#include "ses_oracle_math.h"
+void o_philox_raw(const uint32_t *ctr, const uint32_t *key, uint32_t *out);
+}
+
+#define B2_FN static inline
+#define B2_FN_MEMBER inline
+#define B2_CONST static const
+#define B2_UNROLL
+#define B2_SINCOS(a, s, c) o_sincosf((a), &(s), &(c))
+#define B2_SQRT(x) sqrtf(x)
+#define B2_FLOOR(x) floorf(x)
+#define B2_F2U(f) o_f2u(f)
+
+// two uniforms in (-1, 1) from the episode key and the step counter: the same Philox call as the device
+// (ses_rng.h philox_words(seed, TAG_ENV_STEP, 0, 0, step)); u32_to_unit as in ses_oracle.c
+static inline float b2o_u32_to_unit(uint32_t r) { return o_fma((float)r, 0x1.0p-32f, 0x1.0p-33f); }
+static inline void b2o_dispersion(uint32_t key0, uint32_t key1, int step, float *d0, float *d1)
+{
+    const uint32_t ctr[4] = {(uint32_t)step, 0u, 0u, (uint32_t)(2ull << 24)}, key[2] = {key0, key1};
+    uint32_t r[4];
+    o_philox_raw(ctr, key, r);
+    *d0 = o_fma(b2o_u32_to_unit(r[0]), 2.0f, -1.0f);
+    *d1 = o_fma(b2o_u32_to_unit(r[1]), 2.0f, -1.0f);
+}
+#define B2_DISPERSION(k0, k1, step, d0, d1) b2o_dispersion((k0), (k1), (step), &(d0), &(d1))
+
+#include "ses_lander_env.h"
+
+using namespace b2l;
+
+struct LanderSim {
+    LanderEnv env;
+    float ty[11];
+};
+
+extern "C" {
+
+int o_lander_state_size(void) { return (int)sizeof(LanderSim); }
+
+void o_lander_obs(const void *state, float *obs)
+{
+    float o[8];
+    lander_obs(((const LanderSim *)state)->env, o);
+    memcpy(obs, o, sizeof o);
+}
+
+void o_lander_reset(void *state, const float *u16, float *obs)
+{
+    LanderSim *s = (LanderSim *)state;
+    memset(s, 0, sizeof *s);
+    lander_terrain_heights(u16, s->ty);
+    LanderTerrain terr{s->ty};
+    lander_reset(s->env, terr, u16);
+    if (obs) o_lander_obs(state, obs);
+}
+
+float o_lander_step(void *state, float a0, float a1, float *obs, int32_t *done)
+{
+    LanderSim *s = (LanderSim *)state;
+    LanderTerrain terr{s->ty};
+    bool d;
+    const float r = lander_step(s->env, terr, a0, a1, d);
+    if (obs) o_lander_obs(state, obs);
+    *done = d ? 1 : 0;
+    return r;
+}
+
+// diagnostics for the tests: bodies [3][6] (c, a, v, w), velocity iterations of the last step, limit states, flags
+void o_lander_debug(const void *state, float *bodies, int32_t *ints)
+{
+    const LanderSim *s = (const LanderSim *)state;
+    for (int b = 0; b < 3; ++b) {
+        const Body &B = s->env.w.body[b];
+        const float v[6] = {B.cx, B.cy, B.a, B.vx, B.vy, B.w};
+        memcpy(bodies + 6 * b, v, sizeof v);
+    }
+    ints[0] = 0;
+    ints[1] = s->env.w.joint[0].state;
+    ints[2] = s->env.w.joint[1].state;
+    ints[3] = s->env.w.game_over;
+    ints[4] = s->env.w.awake;
+    ints[5] = s->env.w.ground_contact[1];
+    ints[6] = s->env.w.ground_contact[2];
+    int touching = 0;
+    for (int b = 0; b < 3; ++b)
+        for (int k = 0; k < 2; ++k) touching += s->env.w.mf[b][k].count;
+    ints[7] = touching;
+}
+
+}  // extern "C"

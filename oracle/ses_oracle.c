@@ -577,226 +577,21 @@ void o_rollout_spread(int n_agents, int N, int E, int max_cycles, const float *t
 }
 
 /* ========================================================================================== */
-/* LunarLanderContinuous "lite" (conf/lunarlander_openai.yaml of the reference: GRU policy, 4 tanh outputs of
+/* LunarLanderContinuous-v2 (conf/lunarlander_openai.yaml of the reference: GRU policy, 4 tanh outputs of
  * which the env uses [0] main and [1] side engine, POMDP mask on obs 2,3,5 -- envs/gym_wrapper.py:57-66).
  *
- * gym's LunarLander is a Box2D world (3 bodies, 2 revolute joints, polygon-edge contacts, 180 velocity
- * iterations per step).  Box2D / gym are third-party, absent from the reference tree and from this image, and
- * a faithful port cannot be checked against anything here: PARITY UNPINNED.  What is built instead is a
- * REDUCED rigid-body model with gym's constants, engine model (incl. per-step dispersion noise), terrain
- * generator, observation vector, reward shaping and termination rules, but:
- *   - lander + legs are ONE rigid body (legs frozen at their spring rest angle), origin = centre of mass;
- *   - contacts: the 2 leg tips against the piecewise-linear terrain, sequential impulses (8 iterations,
- *     Baumgarte 0.2, friction 0.1414 = sqrt(0.2*0.1)); any hull vertex touching the terrain = crash;
- *   - a leg tip meeting the terrain with a normal approach speed above 3 m/s = crash (gym's 40 N*m leg springs
- *     absorb about 40 J before the hull hits the ground);
- *   - "body asleep" (+100) = both legs down and |v|, |omega| < 0.05 for 25 consecutive steps.
- * The GPU kernel reproduces THIS definition bit for bit (tests/test_gpu_lander.py).
+ * The env itself -- gym's lunar_lander.py on a Box2D world of three bodies, two revolute joints and polygon /
+ * terrain-edge contacts, world.Step(1/50, 180, 60) per env step -- is restated in ses_b2.h (the world) and
+ * ses_lander_env.h (the env), built as C++ in ses_b2_oracle.cpp; this file drives it through the C entry points
+ * below.  gym / Box2D are third-party, absent from the reference tree and from this image: PARITY UNPINNED at that
+ * boundary (the headers list what is restated and what deviates).  The GPU kernels reproduce THIS definition bit
+ * for bit (tests/test_gpu_lander.py).
  * One initial-state row = 16 uniforms in [0,1): [0,1] initial force, [2..13] terrain heights, [14,15] the
  * episode's dispersion-noise key (bit patterns). */
-#define LL_SCALE 30.0f
-#define LL_DT 0.02f
-#define LL_W 20.0f
-#define LL_H (400.0f / 30.0f)
-#define LL_HELIPAD_Y (400.0f / 30.0f / 4.0f)
-#define LL_MAIN_POWER 13.0f
-#define LL_SIDE_POWER 0.6f
-#define LL_INV_MASS 0x1.9cfee8p-3f       /* 1 / 4.958889  (lander polygon density 5 + two legs density 1) */
-#define LL_INV_INERTIA 0x1.18f758p+0f    /* 1 / 0.9111417 about the centre of mass                         */
-#define LL_TIP_X 0x1.e72fccp-1f          /* leg tip, body frame (+-x) */
-#define LL_TIP_Y (-0x1.13c8b4p-1f)
-#define LL_FRICTION 0.1414f
-#define LL_BAUMGARTE 0.2f
-#define LL_SLOP 0.005f
-#define LL_CRASH_SPEED 3.0f               /* leg-tip approach speed the (frozen) leg springs cannot absorb */
-#define LL_SLEEP_V 0.05f
-#define LL_SLEEP_STEPS 25
-#define TAG_ENV_STEP 2ull
-
-typedef struct {
-    float x, y, vx, vy, ang, om;
-    float prev_shaping;
-    int has_prev, sleep, leg0, leg1;
-    float ty[11];                 /* smoothed terrain heights at x = 0, 2, ..., 20 */
-    uint32_t key[2];
-    int step;
-} lander_t;
-
-static const float LL_HULL[6][2] = {{-14.0f / 30.0f, 17.0f / 30.0f}, {-17.0f / 30.0f, 0.0f}, {-17.0f / 30.0f, -10.0f / 30.0f},
-                                    {17.0f / 30.0f, -10.0f / 30.0f}, {17.0f / 30.0f, 0.0f}, {14.0f / 30.0f, 17.0f / 30.0f}};
-
-static void ll_terrain(float x, const float *ty, float *h, float *nx, float *ny)
-{
-    float fk = floorf(x * 0.5f);
-    fk = o_minf(o_maxf(fk, 0.0f), 9.0f);
-    const int k = (int)fk;
-    const float t = (x - 2.0f * fk) * 0.5f;
-    const float d = ty[k + 1] - ty[k];
-    *h = o_fma(d, t, ty[k]);
-    const float slope = d * 0.5f;
-    const float inv = 1.0f / sqrtf(o_fma(slope, slope, 1.0f));
-    *nx = -slope * inv;
-    *ny = inv;
-}
-
-static void ll_obs(const lander_t *s, float *obs)
-{
-    obs[0] = (s->x - LL_W * 0.5f) / (LL_W * 0.5f);
-    obs[1] = (s->y - (LL_HELIPAD_Y + 18.0f / LL_SCALE)) / (LL_H * 0.5f);
-    obs[2] = s->vx * (LL_W * 0.5f) / 50.0f;
-    obs[3] = s->vy * (LL_H * 0.5f) / 50.0f;
-    obs[4] = s->ang;
-    obs[5] = 20.0f * s->om / 50.0f;
-    obs[6] = s->leg0 ? 1.0f : 0.0f;
-    obs[7] = s->leg1 ? 1.0f : 0.0f;
-}
-
-/* one env step; returns reward, sets *done */
-static float ll_step(lander_t *s, float a0, float a1, int *done)
-{
-    /* engine dispersion noise: 2 uniforms in (-1,1)/SCALE from the episode key and the step counter */
-    uint32_t ctr[4] = {(uint32_t)s->step, 0u, 0u, (uint32_t)(TAG_ENV_STEP << 24)}, r[4];
-    philox4x32_10(ctr, s->key, r);
-    const float d0 = o_fma(u32_to_unit(r[0]), 2.0f, -1.0f) / LL_SCALE;
-    const float d1 = o_fma(u32_to_unit(r[1]), 2.0f, -1.0f) / LL_SCALE;
-    s->step += 1;
-    float sn, cs;
-    o_sincosf(s->ang, &sn, &cs);
-    const float tipx = sn, tipy = cs, sidex = -cs, sidey = sn;
-    float m_power = 0.0f, s_power = 0.0f;
-    a0 = o_minf(o_maxf(a0, -1.0f), 1.0f);
-    a1 = o_minf(o_maxf(a1, -1.0f), 1.0f);
-    if (a0 > 0.0f) {
-        m_power = (o_minf(o_maxf(a0, 0.0f), 1.0f) + 1.0f) * 0.5f;
-        const float ox = o_fma(tipx, 4.0f / LL_SCALE + 2.0f * d0, sidex * d1);
-        const float oy = -(tipy * (4.0f / LL_SCALE + 2.0f * d0)) - sidey * d1;
-        const float jx = -ox * LL_MAIN_POWER * m_power, jy = -oy * LL_MAIN_POWER * m_power;
-        s->vx = o_fma(jx, LL_INV_MASS, s->vx);
-        s->vy = o_fma(jy, LL_INV_MASS, s->vy);
-        s->om = o_fma(ox * jy - oy * jx, LL_INV_INERTIA, s->om);
-    }
-    if (fabsf(a1) > 0.5f) {
-        const float dir = a1 > 0.0f ? 1.0f : -1.0f;
-        s_power = o_minf(o_maxf(fabsf(a1), 0.5f), 1.0f);
-        const float lat = o_fma(3.0f, d1, dir * (12.0f / LL_SCALE));
-        const float ox = o_fma(tipx, d0, sidex * lat);
-        const float oy = -(tipy * d0) - sidey * lat;
-        const float rx = ox - tipx * (17.0f / LL_SCALE), ry = oy + tipy * (14.0f / LL_SCALE);
-        const float jx = -ox * LL_SIDE_POWER * s_power, jy = -oy * LL_SIDE_POWER * s_power;
-        s->vx = o_fma(jx, LL_INV_MASS, s->vx);
-        s->vy = o_fma(jy, LL_INV_MASS, s->vy);
-        s->om = o_fma(rx * jy - ry * jx, LL_INV_INERTIA, s->om);
-    }
-    s->vy = o_fma(-10.0f, LL_DT, s->vy);                       /* gravity */
-
-    /* contacts at the current pose */
-    float crx[2], cry[2], cnx[2], cny[2], cpen[2], ln[2] = {0.0f, 0.0f}, lt[2] = {0.0f, 0.0f};
-    int active[2];
-    for (int i = 0; i < 2; ++i) {
-        const float bx = i == 0 ? LL_TIP_X : -LL_TIP_X, by = LL_TIP_Y;
-        crx[i] = bx * cs - by * sn;
-        cry[i] = bx * sn + by * cs;
-        float h;
-        ll_terrain(s->x + crx[i], s->ty, &h, &cnx[i], &cny[i]);
-        cpen[i] = h - (s->y + cry[i]);
-        active[i] = cpen[i] >= 0.0f;
-    }
-    int crash = 0;
-    for (int i = 0; i < 2; ++i) {
-        const float vn = o_fma(s->vx - s->om * cry[i], cnx[i], o_fma(s->om, crx[i], s->vy) * cny[i]);
-        if (active[i] && vn < -LL_CRASH_SPEED) crash = 1;
-    }
-    for (int k = 0; k < 6; ++k) {
-        const float rx = LL_HULL[k][0] * cs - LL_HULL[k][1] * sn, ry = LL_HULL[k][0] * sn + LL_HULL[k][1] * cs;
-        float h, nx, ny;
-        ll_terrain(s->x + rx, s->ty, &h, &nx, &ny);
-        if (h - (s->y + ry) >= 0.0f) crash = 1;
-    }
-    for (int it = 0; it < 8; ++it)
-        for (int i = 0; i < 2; ++i) {
-            if (!active[i]) continue;
-            const float rx = crx[i], ry = cry[i], nx = cnx[i], ny = cny[i];
-            /* normal */
-            float vpx = s->vx - s->om * ry, vpy = o_fma(s->om, rx, s->vy);
-            const float rn = rx * ny - ry * nx;
-            const float kn = o_fma(rn * rn, LL_INV_INERTIA, LL_INV_MASS);
-            const float bias = (LL_BAUMGARTE / LL_DT) * o_maxf(cpen[i] - LL_SLOP, 0.0f);
-            float lam = -(o_fma(vpx, nx, vpy * ny) - bias) / kn;
-            const float nl = o_maxf(ln[i] + lam, 0.0f);
-            lam = nl - ln[i];
-            ln[i] = nl;
-            s->vx = o_fma(lam * nx, LL_INV_MASS, s->vx);
-            s->vy = o_fma(lam * ny, LL_INV_MASS, s->vy);
-            s->om = o_fma(rn * lam, LL_INV_INERTIA, s->om);
-            /* friction along t = (ny, -nx) */
-            vpx = s->vx - s->om * ry; vpy = o_fma(s->om, rx, s->vy);
-            const float tx = ny, tyv = -nx;
-            const float rt = rx * tyv - ry * tx;
-            const float kt = o_fma(rt * rt, LL_INV_INERTIA, LL_INV_MASS);
-            float lamt = -o_fma(vpx, tx, vpy * tyv) / kt;
-            const float lim = LL_FRICTION * ln[i];
-            const float ntl = o_minf(o_maxf(lt[i] + lamt, -lim), lim);
-            lamt = ntl - lt[i];
-            lt[i] = ntl;
-            s->vx = o_fma(lamt * tx, LL_INV_MASS, s->vx);
-            s->vy = o_fma(lamt * tyv, LL_INV_MASS, s->vy);
-            s->om = o_fma(rt * lamt, LL_INV_INERTIA, s->om);
-        }
-    s->x = o_fma(s->vx, LL_DT, s->x);
-    s->y = o_fma(s->vy, LL_DT, s->y);
-    s->ang = o_fma(s->om, LL_DT, s->ang);
-    s->leg0 = active[0];
-    s->leg1 = active[1];
-    const float speed2 = o_fma(s->vx, s->vx, s->vy * s->vy);
-    const int still = active[0] && active[1] && speed2 < LL_SLEEP_V * LL_SLEEP_V && fabsf(s->om) < LL_SLEEP_V;
-    s->sleep = still ? s->sleep + 1 : 0;
-
-    float obs[8];
-    ll_obs(s, obs);
-    const float shaping = -100.0f * sqrtf(o_fma(obs[0], obs[0], obs[1] * obs[1])) -
-                          100.0f * sqrtf(o_fma(obs[2], obs[2], obs[3] * obs[3])) - 100.0f * fabsf(obs[4]) +
-                          10.0f * obs[6] + 10.0f * obs[7];
-    float reward = s->has_prev ? shaping - s->prev_shaping : 0.0f;
-    s->prev_shaping = shaping;
-    s->has_prev = 1;
-    reward = reward - m_power * 0.30f;
-    reward = reward - s_power * 0.03f;
-    *done = 0;
-    if (crash || fabsf(obs[0]) >= 1.0f) { *done = 1; reward = -100.0f; }
-    if (s->sleep >= LL_SLEEP_STEPS) { *done = 1; reward = 100.0f; }
-    return reward;
-}
-
-/* reset from one row of 16 uniforms; like gym, reset() ends with one no-op step whose observation is returned */
-static void ll_reset(lander_t *s, const float *u)
-{
-    float height[12];
-    for (int i = 0; i < 12; ++i) height[i] = u[2 + i] * (LL_H * 0.5f);
-    for (int i = 3; i <= 7; ++i) height[i] = LL_HELIPAD_Y;
-    for (int i = 0; i < 11; ++i) s->ty[i] = 0.33f * ((height[i == 0 ? 11 : i - 1] + height[i]) + height[i + 1]);
-    s->x = LL_W * 0.5f; s->y = LL_H;
-    s->vx = (o_fma(u[0], 2.0f, -1.0f) * 1000.0f) * LL_INV_MASS * LL_DT;    /* INITIAL_RANDOM force for one step */
-    s->vy = (o_fma(u[1], 2.0f, -1.0f) * 1000.0f) * LL_INV_MASS * LL_DT;
-    s->ang = 0.0f; s->om = 0.0f;
-    s->prev_shaping = 0.0f; s->has_prev = 0; s->sleep = 0; s->leg0 = 0; s->leg1 = 0;
-    memcpy(&s->key[0], &u[14], 4);
-    memcpy(&s->key[1], &u[15], 4);
-    s->step = 0;
-    int done;
-    (void)ll_step(s, 0.0f, 0.0f, &done);
-}
-
-/* single-env entry points for the Python env object: state blob = the struct itself */
-int o_lander_state_size(void) { return (int)sizeof(lander_t); }
-void o_lander_reset(void *state, const float *u16, float *obs) { ll_reset((lander_t *)state, u16); ll_obs((lander_t *)state, obs); }
-float o_lander_step(void *state, float a0, float a1, float *obs, int32_t *done)
-{
-    int d;
-    const float r = ll_step((lander_t *)state, a0, a1, &d);
-    ll_obs((lander_t *)state, obs);
-    *done = d;
-    return r;
-}
+int o_lander_state_size(void);
+void o_lander_reset(void *state, const float *u16, float *obs);
+float o_lander_step(void *state, float a0, float a1, float *obs, int32_t *done);
+void o_lander_obs(const void *state, float *obs);
 
 /* population rollout: GRU or MLP policy with 4 continuous (tanh) outputs, POMDP mask bits over the 8 obs */
 void o_rollout_lander(int gru, int N, int E, int max_step, uint32_t obs_mask, const float *theta, const float *init,
@@ -804,21 +599,22 @@ void o_rollout_lander(int gru, int N, int E, int max_step, uint32_t obs_mask, co
 {
     const int S = 8, A = 4;
     const int P = o_param_count(S, A, gru);
+    void *st = malloc((size_t)o_lander_state_size());
     for (int i = 0; i < N; ++i) {
         net_view v = view_params(theta + (size_t)i * P, S, A, gru);
         double total = 0.0;
         for (int e = 0; e < E; ++e) {
-            lander_t st;
-            ll_reset(&st, init + ((size_t)(init_per_offspring ? i : 0) * E + e) * 16);
+            float obs[8];
+            o_lander_reset(st, init + ((size_t)(init_per_offspring ? i : 0) * E + e) * 16, obs);
             float h[SES_H] = {0};
             double ret = 0.0;
-            int steps = 0, done = 0;
+            int steps = 0;
+            int32_t done = 0;
             while (!done && steps < max_step) {
-                float obs[8], logits[SES_MAX_A], act[SES_MAX_A];
-                ll_obs(&st, obs);
+                float logits[SES_MAX_A], act[SES_MAX_A];
                 for (int k = 0; k < 8; ++k) if ((obs_mask >> k) & 1u) obs[k] = 0.0f;
                 (void)policy_forward(&v, S, A, 0, gru, obs, h, logits, act);
-                ret += (double)ll_step(&st, act[0], act[1], &done);
+                ret += (double)o_lander_step(st, act[0], act[1], obs, &done);
                 steps += 1;
             }
             ep_return[(size_t)i * E + e] = ret;
@@ -827,4 +623,5 @@ void o_rollout_lander(int gru, int N, int E, int max_step, uint32_t obs_mask, co
         }
         fitness[i] = (float)(total / (double)E);
     }
+    free(st);
 }

@@ -344,17 +344,17 @@ struct LanderLs {
     };
     __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u, int slot)
     {
-        __shared__ float4 seg[4][GM_EB][LL_SEGMENTS];          // one terrain table per (wave, episode slot)
-        ll_reset(s.st, u, seg[threadIdx.x >> 6][slot]);
+        __shared__ float terrain[4][GM_EB][LL_TERRAIN_ROW];    // one terrain row per (wave, episode slot)
+        ll_reset(s.st, u, terrain[threadIdx.x >> 6][slot]);
     }
     __device__ static __forceinline__ void observe(const State &s, float (&obs)[S]) { ll_obs(s.st, obs); }
     __device__ static __forceinline__ float step(State &s, const float (&logits)[A], const TanhEntry *tab, bool freeze,
                                                  bool &done)
     {
         const float a0 = tanh_(tab, logits[0]), a1 = tanh_(tab, logits[1]);
-        LanderState ns = s.st;
-        const float r = ll_step(ns, a0, a1, done);
-        if (!freeze) s.st = ns;
+        float r = 0.0f;
+        done = true;
+        if (!freeze) r = ll_step(s.st, a0, a1, done);          // a finished env is frozen (the env code has no wave votes)
         return r;
     }
 };
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void k_rollout_gru_mfma(const float *__rest
     }
 }
 
-// LunarLander-lite: continuous control (tanh head, the env uses outputs 0 and 1 -- SURVEY 3.4-12), float
+// LunarLanderContinuous-v2 (ses_lander.h): continuous control (tanh head, the env uses outputs 0 and 1 -- SURVEY 3.4-12), float
 // rewards accumulated in float64 like the reference's python sum (loop.py:123).  GRU: one offspring per wave
 // (the env is wave-uniform, so contact iterations are skipped by scalar branches while the lander is in
 // flight); MLP: 8 lanes per env.
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void k_rollout_lander(const float *__restrict_
     constexpr int S = 8, A = 4, LPE = 8;
     __shared__ TanhEntry tanh_tab[SES_TANH_N];
     __shared__ __attribute__((aligned(16))) float vecs[4][64];
-    __shared__ float4 seg[256 / LPE][LL_SEGMENTS];                // terrain tables: GRU one per wave, MLP one per env
+    __shared__ float terrain[256 / LPE][LL_TERRAIN_ROW];          // terrain rows: GRU one per wave, MLP one per env
     stage_tanh_table(tanh_tab);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if constexpr (GRU) {
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void k_rollout_lander(const float *__restrict_
         float *vec = vecs[wave];
         for (int ep = ep_begin; ep < ep_end; ++ep) {
             LanderState st;
-            ll_reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 16, seg[wave]);
+            ll_reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 16, terrain[wave]);
             float h = 0.0f;
             wave_lds_sync();
             if (lane < 32) vec[32 + lane] = 0.0f;
@@ -602,22 +602,25 @@ __global__ __launch_bounds__(256) void k_rollout_lander(const float *__restrict_
         MlpSlice<S, A, LPE> net;
         net.load(theta + (size_t)row * P, sub);
         LanderState st;
-        ll_reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 16, seg[threadIdx.x / LPE]);
+        ll_reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 16, terrain[threadIdx.x / LPE]);
         double ret = 0.0;
         int steps = 0;
         bool done = false;
         for (int t = 0; t < max_step; ++t) {
             if (__ballot(!done) == 0ull) break;
+            // the lane's weight slice is re-read from the (L2-resident) row every step: 56 loads next to a 36 k
+            // instruction world step, and nothing of the policy has to stay in registers across it
+            net.load(theta + (size_t)row * P, sub);
             float obs[S], logits[A];
             ll_obs(st, obs);
 #pragma unroll
             for (int k = 0; k < S; ++k) obs[k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
             net.forward(tanh_tab, obs, logits);
             const float a0 = tanh_(tanh_tab, logits[0]), a1 = tanh_(tanh_tab, logits[1]);
-            LanderState ns = st;
-            bool nd;
-            const float r = ll_step(ns, a0, a1, nd);
-            if (!done) { st = ns; ret += (double)r; steps += 1; done = nd; }   // a finished env is frozen
+            if (!done) {                                           // a finished env is frozen
+                ret += (double)ll_step(st, a0, a1, done);
+                steps += 1;
+            }
         }
         if (valid && sub == 0) {
             ep_return[env] = ret;

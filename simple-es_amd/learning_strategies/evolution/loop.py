@@ -42,7 +42,7 @@ class ESLoop(BaseESLoop):
         # env.fixed_length: the synchronous-benchmark mode of the rollout kernels (termination masked: finished envs
         # keep stepping, rewards gated; identical returns, data-independent work).  Default: episodic, like the reference.
         self.mode = MODE_FIXED_LENGTH if env_cfg.get("fixed_length", False) else MODE_EPISODIC
-        self.env_variant = getattr(env, "variant", None)     # e.g. "lander-lite": a reduced model stands in for the gym env
+        self.env_variant = getattr(env, "variant", None)     # e.g. "box2d-restated": third-party physics restated, unpinned
         self.history = []
         self._metrics = None
         self._events = None
@@ -137,7 +137,8 @@ class ESLoop(BaseESLoop):
         offsprings = self.offspring_strategy.init_offspring(self.network, self.env.get_agent_ids())
         rank0 = offsprings.shard.rank == 0
         if rank0 and self.env_variant:
-            print(f"note: {self.env.name} runs on the {self.env_variant} model of this build (see README: not Box2D)")
+            print(f"note: {self.env.name} runs on this build's restatement of its third-party physics "
+                  f"({self.env_variant}; parity with gym / Box2D is unpinned, see README)")
         pending = None
         self._last_report = 0.0
         for ep_num in range(1, self.generation_num + 1):

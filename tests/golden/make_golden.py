@@ -304,15 +304,15 @@ def g7_spread():
 # --------------------------------------------------------------------------- G8 (continuous control, GRU)
 def g8_lander():
     """conf/lunarlander_openai.yaml shape: GymEnvModel(8, 4, discrete_action=False, gru=True), POMDP mask,
-    max_step 300, reference RolloutWorker over the build's LunarLander-lite env."""
-    from oracle.lander_env import LunarLanderLiteEnv
+    max_step 300, reference RolloutWorker over the build's LunarLanderContinuous-v2 env (oracle/lander_env.py)."""
+    from oracle.lander_env import LunarLanderEnv
     E = 3
     rng = np.random.RandomState(8)
     net = GymEnvModel(8, 4, False, True)
     P = flat(net).size
     theta = (rng.standard_normal((24, P)) * rng.choice([0.05, 0.2, 0.5], size=(24, 1))).astype(np.float32)
     init = rng.rand(E, 16).astype(np.float32)
-    env = LunarLanderLiteEnv(init, max_step=300, pomdp=True)
+    env = LunarLanderEnv(init, max_step=300, pomdp=True)
     rets = []
     for i in range(theta.shape[0]):
         load_flat(net, theta[i])

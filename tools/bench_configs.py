@@ -79,10 +79,10 @@ def main():
     es.close()
 
     es = HipES("LunarLanderContinuous-v2", 8, 4, False, True, pomdp=True, max_step=300, eval_ep_num=5)
-    rollout_case("C3 LunarLander(lite) POMDP GRU (conf/lunarlander_openai.yaml)", es, n, 0.168, MODE_EPISODIC, reps)
+    rollout_case("C3 LunarLanderContinuous-v2 POMDP GRU (conf/lunarlander_openai.yaml)", es, n, 0.168, MODE_EPISODIC, reps)
     es.close()
     es = HipES("LunarLanderContinuous-v2", 8, 4, False, False, pomdp=False, max_step=300, eval_ep_num=5)
-    rollout_case("LunarLander(lite) MLP (conf/lunarlander.yaml)", es, n, 2.0, MODE_EPISODIC, reps)
+    rollout_case("LunarLanderContinuous-v2 MLP (conf/lunarlander.yaml)", es, n, 2.0, MODE_EPISODIC, reps)
     es.close()
 
     for agents, S in ((3, 18), (2, 12)):
