@@ -16,7 +16,8 @@
 //     two-point block solver and restitution 0, b2RevoluteJoint with limit + motor, warm starting, N velocity
 //     iterations, position integration with the translation / rotation caps, up to M position iterations with
 //     Box2D's own early exit, island sleep timer);
-//   * float32 throughout, no fused multiply-add (Box2D is built without contraction), IEEE division and sqrt.
+//   * float32 throughout, IEEE division and sqrt.  Box2D's x86 build rounds every product separately; so does this
+//     file, except in the two innermost loops (joint and contact velocity iterations), which use fused multiply-adds.
 // Not restated (documented deviations): continuous collision (b2World::SolveTOI), the broad phase (every terrain edge
 // whose x-range the fattened polygon AABB overlaps is a candidate -- same touching set), Box2D's island traversal
 // order (here: joints in definition order, then contacts by body, then by manifold slot), sinf / cosf of the C
@@ -25,7 +26,7 @@
 // All N velocity iterations are run, as in Box2D: with the light legs on the heavy hull the joint rows converge by
 // about 3 % per iteration (measured), a fixed point is not reached earlier.  Quantities that Box2D recomputes in every
 // iteration from values that do not change during a step (the inverse of the joint's 3x3 mass matrix) are computed once
-// per step and applied as a matrix-vector product.
+// per step and applied as a matrix-vector product: same algorithm, results differ from Box2D's at rounding level.
 #pragma once
 #include <stdint.h>
 
@@ -86,9 +87,9 @@ struct Joint {                       // b2RevoluteJoint, the part that lives acr
 struct JointTmp {                    // InitVelocityConstraints results, alive for one step
     float rax, ray, rbx, rby;
     float ezx, ezy;                  // m_mass.ez.x, .ez.y (the limit-release right-hand side)
-    float i00, i01, i02, i11, i12, i22;   // inverse of the symmetric 3x3 m_mass
+    float n00, n01, n02, n11, n12, n22;   // MINUS the inverse of the symmetric 3x3 m_mass
     float j00, j01, j11;             // inverse of its upper-left 2x2 block
-    float motor_mass;
+    float motor_mass, max_impulse;   // max_impulse = dt * maxMotorTorque
 };
 
 struct Manifold {                    // b2Manifold of (terrain edge `edge`, this body's polygon) + solver temporaries
@@ -379,7 +380,7 @@ B2_FN void collide(World<D> &w, const T &terr)
 // ------------------------------------------------------------------------------------------------------------------
 // b2RevoluteJoint
 template <class D>
-B2_FN void joint_init(World<D> &w, int j, JointTmp &t)
+B2_FN void joint_init(World<D> &w, int j, JointTmp &t, float dt)
 {
     const JointDef &jd = D::joint()[j];
     Joint &J = w.joint[j];
@@ -405,13 +406,15 @@ B2_FN void joint_init(World<D> &w, int j, JointTmp &t)
         float det = exx * c00 + eyx * c01 + ezx * c02;
         if (det != 0.0f) det = 1.0f / det;
         const float c11 = exx * ezz - ezx * ezx, c12 = eyx * ezx - exx * ezy, c22 = exx * eyy - eyx * eyx;
-        t.i00 = det * c00; t.i01 = det * c01; t.i02 = det * c02; t.i11 = det * c11; t.i12 = det * c12; t.i22 = det * c22;
+        t.n00 = -(det * c00); t.n01 = -(det * c01); t.n02 = -(det * c02);
+        t.n11 = -(det * c11); t.n12 = -(det * c12); t.n22 = -(det * c22);
         float d2 = exx * eyy - eyx * eyx;                    // b2Mat33::Solve22
         if (d2 != 0.0f) d2 = 1.0f / d2;
         t.j00 = d2 * eyy; t.j01 = -d2 * eyx; t.j11 = d2 * exx;
     }
     t.motor_mass = iA + iB;
     if (t.motor_mass > 0.0f) t.motor_mass = 1.0f / t.motor_mass;
+    t.max_impulse = dt * J.max_torque;
     {
         const float angle = B.a - A.a;                       // referenceAngle = 0
         if (b2abs(jd.upper - jd.lower) < 2.0f * ANGULAR_SLOP) {
@@ -427,6 +430,10 @@ B2_FN void joint_init(World<D> &w, int j, JointTmp &t)
             J.iz = 0.0f;
         }
     }
+    if (J.state == LIMIT_INACTIVE) {      // no limit row this step: the point rows alone (2x2 block), written in the
+        t.n00 = -t.j00; t.n01 = -t.j01; t.n11 = -t.j11;        // same form so that the iteration below has one path
+        t.n02 = 0.0f; t.n12 = 0.0f; t.n22 = 0.0f;
+    }
     // warm start (dtRatio = 1 for a constant time step: 50.0f * 0.02f rounds to 1.0f)
     const float Px = J.ix, Py = J.iy;
     A.vx -= mA * Px; A.vy -= mA * Py;
@@ -435,51 +442,48 @@ B2_FN void joint_init(World<D> &w, int j, JointTmp &t)
     B.w += iB * ((t.rbx * Py - t.rby * Px) + J.im + J.iz);
 }
 
+// One velocity iteration of the joint: motor row, then the point rows together with the limit row (b2RevoluteJoint::
+// SolveVelocityConstraints).  This is the innermost loop of the world (180 x NJ per step), so it is written with fused
+// multiply-adds and the pre-negated inverse mass matrix; Box2D's x86 build rounds every product separately.
 template <class D>
-B2_FN void joint_solve_velocity(World<D> &w, int j, const JointTmp &t, float dt)
+B2_FN void joint_solve_velocity(World<D> &w, int j, const JointTmp &t)
 {
     const JointDef &jd = D::joint()[j];
     Joint &J = w.joint[j];
     const BodyDef &da = D::body()[jd.a], &db = D::body()[jd.b];
     Body &A = w.body[jd.a], &B = w.body[jd.b];
     const float mA = da.inv_mass, mB = db.inv_mass, iA = da.inv_i, iB = db.inv_i;
-    if (J.state != LIMIT_EQUAL) {                             // motor (enableMotor = true)
-        const float Cdot = B.w - A.w - J.motor_speed;
-        float impulse = -t.motor_mass * Cdot;
+    const bool equal_limits = b2abs(jd.upper - jd.lower) < 2.0f * ANGULAR_SLOP;   // a constant of the joint
+    if (!equal_limits) {                                      // motor (enableMotor = true)
+        const float Cdot = (B.w - A.w) - J.motor_speed;
         const float old = J.im;
-        const float max_impulse = dt * J.max_torque;
-        J.im = b2clamp(old + impulse, -max_impulse, max_impulse);
-        impulse = J.im - old;
-        A.w -= iA * impulse;
-        B.w += iB * impulse;
+        J.im = b2clamp(__builtin_fmaf(-t.motor_mass, Cdot, old), -t.max_impulse, t.max_impulse);
+        const float impulse = J.im - old;
+        A.w = __builtin_fmaf(-iA, impulse, A.w);
+        B.w = __builtin_fmaf(iB, impulse, B.w);
     }
-    const float c1x = (B.vx - B.w * t.rby) - (A.vx - A.w * t.ray);
-    const float c1y = (B.vy + B.w * t.rbx) - (A.vy + A.w * t.rax);
-    float ix, iy, iz = 0.0f;
-    if (J.state != LIMIT_INACTIVE) {
-        const float c2 = B.w - A.w;
-        ix = -(t.i00 * c1x + t.i01 * c1y + t.i02 * c2);
-        iy = -(t.i01 * c1x + t.i11 * c1y + t.i12 * c2);
-        iz = -(t.i02 * c1x + t.i12 * c1y + t.i22 * c2);
-        if (J.state != LIMIT_EQUAL) {
-            const float new_impulse = J.iz + iz;
-            const bool release = J.state == LIMIT_LOWER ? new_impulse < 0.0f : new_impulse > 0.0f;
-            if (release) {                                     // the limit lets go: solve the point rows alone
-                const float rx = -c1x + J.iz * t.ezx, ry = -c1y + J.iz * t.ezy;
-                ix = t.j00 * rx + t.j01 * ry;
-                iy = t.j01 * rx + t.j11 * ry;
-                iz = -J.iz;
-            }
+    const float c1x = __builtin_fmaf(-B.w, t.rby, B.vx) - __builtin_fmaf(-A.w, t.ray, A.vx);
+    const float c1y = __builtin_fmaf(B.w, t.rbx, B.vy) - __builtin_fmaf(A.w, t.rax, A.vy);
+    const float c2 = B.w - A.w;
+    // impulse = -M^-1 Cdot: 3x3 with an active limit, the 2x2 block padded with zeros without (joint_init)
+    float ix = __builtin_fmaf(t.n00, c1x, __builtin_fmaf(t.n01, c1y, t.n02 * c2));
+    float iy = __builtin_fmaf(t.n01, c1x, __builtin_fmaf(t.n11, c1y, t.n12 * c2));
+    float iz = __builtin_fmaf(t.n02, c1x, __builtin_fmaf(t.n12, c1y, t.n22 * c2));
+    if (!equal_limits) {
+        const float new_impulse = J.iz + iz;                  // (inactive limit: J.iz = iz = 0, never released)
+        const bool release = J.state == LIMIT_LOWER ? new_impulse < 0.0f : new_impulse > 0.0f;
+        if (release) {                                         // the limit lets go: solve the point rows alone
+            const float rx = __builtin_fmaf(J.iz, t.ezx, -c1x), ry = __builtin_fmaf(J.iz, t.ezy, -c1y);
+            ix = __builtin_fmaf(t.j00, rx, t.j01 * ry);
+            iy = __builtin_fmaf(t.j01, rx, t.j11 * ry);
+            iz = -J.iz;
         }
-    } else {
-        ix = -(t.j00 * c1x + t.j01 * c1y);
-        iy = -(t.j01 * c1x + t.j11 * c1y);
     }
     J.ix += ix; J.iy += iy; J.iz += iz;
-    A.vx -= mA * ix; A.vy -= mA * iy;
-    A.w -= iA * ((t.rax * iy - t.ray * ix) + iz);
-    B.vx += mB * ix; B.vy += mB * iy;
-    B.w += iB * ((t.rbx * iy - t.rby * ix) + iz);
+    A.vx = __builtin_fmaf(-mA, ix, A.vx); A.vy = __builtin_fmaf(-mA, iy, A.vy);
+    A.w = __builtin_fmaf(-iA, __builtin_fmaf(t.rax, iy, -(t.ray * ix)) + iz, A.w);
+    B.vx = __builtin_fmaf(mB, ix, B.vx); B.vy = __builtin_fmaf(mB, iy, B.vy);
+    B.w = __builtin_fmaf(iB, __builtin_fmaf(t.rbx, iy, -(t.rby * ix)) + iz, B.w);
 }
 
 template <class D>
@@ -617,45 +621,43 @@ B2_FN void contact_solve_velocity(Manifold &m, const ContactTmp &t, Body &B, con
     B2_UNROLL
     for (int i = 0; i < 2; ++i) {                              // friction first
         if (i < t.vcount) {
-            const float dvx = B.vx - B.w * t.rby[i], dvy = B.vy + B.w * t.rbx[i];
-            const float vt = dvx * tx + dvy * ty;
-            float lambda = t.tmass[i] * (-vt);
+            const float dvx = __builtin_fmaf(-B.w, t.rby[i], B.vx), dvy = __builtin_fmaf(B.w, t.rbx[i], B.vy);
+            const float vt = __builtin_fmaf(dvx, tx, dvy * ty);
             const float max_friction = friction * m.ni[i];
-            const float new_impulse = b2clamp(m.ti[i] + lambda, -max_friction, max_friction);
-            lambda = new_impulse - m.ti[i];
+            const float new_impulse = b2clamp(__builtin_fmaf(-t.tmass[i], vt, m.ti[i]), -max_friction, max_friction);
+            const float lambda = new_impulse - m.ti[i];
             m.ti[i] = new_impulse;
             const float Px = lambda * tx, Py = lambda * ty;
-            B.vx += mB * Px; B.vy += mB * Py;
-            B.w += iB * (t.rbx[i] * Py - t.rby[i] * Px);
+            B.vx = __builtin_fmaf(mB, Px, B.vx); B.vy = __builtin_fmaf(mB, Py, B.vy);
+            B.w = __builtin_fmaf(iB, __builtin_fmaf(t.rbx[i], Py, -(t.rby[i] * Px)), B.w);
         }
     }
     if (t.vcount == 1) {
-        const float dvx = B.vx - B.w * t.rby[0], dvy = B.vy + B.w * t.rbx[0];
-        const float vn = dvx * nx + dvy * ny;
-        float lambda = -t.nmass[0] * vn;
-        const float new_impulse = b2max(m.ni[0] + lambda, 0.0f);
-        lambda = new_impulse - m.ni[0];
+        const float dvx = __builtin_fmaf(-B.w, t.rby[0], B.vx), dvy = __builtin_fmaf(B.w, t.rbx[0], B.vy);
+        const float vn = __builtin_fmaf(dvx, nx, dvy * ny);
+        const float new_impulse = b2max(__builtin_fmaf(-t.nmass[0], vn, m.ni[0]), 0.0f);
+        const float lambda = new_impulse - m.ni[0];
         m.ni[0] = new_impulse;
         const float Px = lambda * nx, Py = lambda * ny;
-        B.vx += mB * Px; B.vy += mB * Py;
-        B.w += iB * (t.rbx[0] * Py - t.rby[0] * Px);
+        B.vx = __builtin_fmaf(mB, Px, B.vx); B.vy = __builtin_fmaf(mB, Py, B.vy);
+        B.w = __builtin_fmaf(iB, __builtin_fmaf(t.rbx[0], Py, -(t.rby[0] * Px)), B.w);
     } else {                                                   // block solver (b2ContactSolver.cpp, the four cases)
         const float ax = m.ni[0], ay = m.ni[1];
-        const float dv1x = B.vx - B.w * t.rby[0], dv1y = B.vy + B.w * t.rbx[0];
-        const float dv2x = B.vx - B.w * t.rby[1], dv2y = B.vy + B.w * t.rbx[1];
-        float bx = dv1x * nx + dv1y * ny, by = dv2x * nx + dv2y * ny;
-        bx -= t.k11 * ax + t.k12 * ay;
-        by -= t.k12 * ax + t.k22 * ay;
-        float xx = -(t.b11 * bx + t.b12 * by), xy = -(t.b21 * bx + t.b22 * by);      // case 1
+        const float dv1x = __builtin_fmaf(-B.w, t.rby[0], B.vx), dv1y = __builtin_fmaf(B.w, t.rbx[0], B.vy);
+        const float dv2x = __builtin_fmaf(-B.w, t.rby[1], B.vx), dv2y = __builtin_fmaf(B.w, t.rbx[1], B.vy);
+        float bx = __builtin_fmaf(dv1x, nx, dv1y * ny), by = __builtin_fmaf(dv2x, nx, dv2y * ny);
+        bx -= __builtin_fmaf(t.k11, ax, t.k12 * ay);
+        by -= __builtin_fmaf(t.k12, ax, t.k22 * ay);
+        float xx = -__builtin_fmaf(t.b11, bx, t.b12 * by), xy = -__builtin_fmaf(t.b21, bx, t.b22 * by);      // case 1
         bool solved = xx >= 0.0f && xy >= 0.0f;
         if (!solved) {                                         // case 2
             xx = -t.nmass[0] * bx; xy = 0.0f;
-            const float vn2 = t.k12 * xx + by;
+            const float vn2 = __builtin_fmaf(t.k12, xx, by);
             solved = xx >= 0.0f && vn2 >= 0.0f;
         }
         if (!solved) {                                         // case 3
             xx = 0.0f; xy = -t.nmass[1] * by;
-            const float vn1 = t.k12 * xy + bx;
+            const float vn1 = __builtin_fmaf(t.k12, xy, bx);
             solved = xy >= 0.0f && vn1 >= 0.0f;
         }
         if (!solved) {                                         // case 4
@@ -665,8 +667,8 @@ B2_FN void contact_solve_velocity(Manifold &m, const ContactTmp &t, Body &B, con
         if (solved) {
             const float dx = xx - ax, dy = xy - ay;
             const float P1x = dx * nx, P1y = dx * ny, P2x = dy * nx, P2y = dy * ny;
-            B.vx += mB * (P1x + P2x); B.vy += mB * (P1y + P2y);
-            B.w += iB * ((t.rbx[0] * P1y - t.rby[0] * P1x) + (t.rbx[1] * P2y - t.rby[1] * P2x));
+            B.vx = __builtin_fmaf(mB, P1x + P2x, B.vx); B.vy = __builtin_fmaf(mB, P1y + P2y, B.vy);
+            B.w = __builtin_fmaf(iB, __builtin_fmaf(t.rbx[0], P1y, -(t.rby[0] * P1x)) + __builtin_fmaf(t.rbx[1], P2y, -(t.rby[1] * P2x)), B.w);
             m.ni[0] = xx; m.ni[1] = xy;
         }
     }
@@ -745,13 +747,13 @@ B2_FN void world_step(World<D> &w, const T &terr, float dt)
         for (int s = 0; s < D::NSLOT; ++s) contact_warm_start(w.mf[b][s], ct[b - D::FIRST_SOLVED][s], w.body[b], D::body()[b]);
     }
     B2_UNROLL
-    for (int j = 0; j < D::NJ; ++j) joint_init(w, j, jt[j]);
+    for (int j = 0; j < D::NJ; ++j) joint_init(w, j, jt[j], dt);
 
     // (no wave-level votes anywhere in this file: a world only ever looks at its own state, so the code may run
     //  under any divergence; in flight the contact rows are skipped as a whole)
     for (int it = 0; it < D::VEL_ITERS; ++it) {
         B2_UNROLL
-        for (int j = 0; j < D::NJ; ++j) joint_solve_velocity(w, j, jt[j], dt);
+        for (int j = 0; j < D::NJ; ++j) joint_solve_velocity(w, j, jt[j]);
         if (any_contact) {
             B2_UNROLL
             for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {

@@ -411,18 +411,22 @@ __device__ __forceinline__ void gru_lockstep_batch(const TanhEntry *tanh_tab, Gr
     }
 }
 
-template <typename EnvT, bool FIXED_LENGTH>
-__global__ __launch_bounds__(256) void k_rollout_gru_lockstep(const float *__restrict__ theta,
+// WAVES offspring per workgroup (they share one copy of the tanh table and never synchronise).  CartPole: 4.
+// LunarLander: 1 -- a wave lives as long as the longest of its episodes, a workgroup as long as its longest wave, and
+// with a 20 000-instruction env step the tail is what the kernel time is made of: single-wave workgroups free their
+// SIMD slot for the next offspring as soon as their own five episodes are over.
+template <typename EnvT, bool FIXED_LENGTH, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void k_rollout_gru_lockstep(const float *__restrict__ theta,
                                                               const float *__restrict__ init, int init_per_offspring,
                                                               int n_rows, int E, int P, int max_step, uint32_t obs_mask,
                                                               double *__restrict__ ep_return,
                                                               int32_t *__restrict__ ep_steps)
 {
     __shared__ TanhEntry tanh_tab[SES_TANH_N];
-    __shared__ __attribute__((aligned(16))) GruLockstepLds<EnvT::S, EnvT::A> ldsv[4];
+    __shared__ __attribute__((aligned(16))) GruLockstepLds<EnvT::S, EnvT::A> ldsv[WAVES];
     stage_tanh_table(tanh_tab);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int row = blockIdx.x * 4 + wave;
+    int row = blockIdx.x * WAVES + wave;
     const bool valid = row < n_rows;
     row = valid ? row : n_rows - 1;
     GruLockstepLds<EnvT::S, EnvT::A> &lds = ldsv[wave];
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void k_rollout_gru_mfma(const float *__rest
 // (the env is wave-uniform, so contact iterations are skipped by scalar branches while the lander is in
 // flight); MLP: 8 lanes per env.
 template <bool GRU>
-__global__ __launch_bounds__(256) void k_rollout_lander(const float *__restrict__ theta,
+__global__ __launch_bounds__(256, 2) void k_rollout_lander(const float *__restrict__ theta,
                                                         const float *__restrict__ init, int init_per_offspring,
                                                         int n_rows, int E, int P, int max_step, uint32_t obs_mask,
                                                         double *__restrict__ ep_return, int32_t *__restrict__ ep_steps,
@@ -965,7 +969,7 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
                                h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
                                h->cfg.max_step, h->obs_mask, epr, ep_steps);
         else if (h->cfg.gru && !gru_sequential())
-            hipLaunchKernelGGL((k_rollout_gru_lockstep<LanderLs, false>), dim3(ceil_div(n_rows, 4)), dim3(256), 0,
+            hipLaunchKernelGGL((k_rollout_gru_lockstep<LanderLs, false, 1>), dim3(n_rows), dim3(64), 0,
                                h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
                                h->cfg.max_step, h->obs_mask, epr, ep_steps);
         else if (h->cfg.gru)
@@ -992,10 +996,10 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
         if (h->cfg.gru) {
             const int blocks = ceil_div(n_rows, 4);
             if (fixed)
-                hipLaunchKernelGGL((k_rollout_gru_lockstep<CartPoleLs64, true>), dim3(blocks), dim3(256), 0, h->stream,
+                hipLaunchKernelGGL((k_rollout_gru_lockstep<CartPoleLs64, true, 4>), dim3(blocks), dim3(256), 0, h->stream,
                                    theta, init, init_per_offspring, n_rows, E, h->P, T, h->obs_mask, epr, ep_steps);
             else
-                hipLaunchKernelGGL((k_rollout_gru_lockstep<CartPoleLs64, false>), dim3(blocks), dim3(256), 0, h->stream,
+                hipLaunchKernelGGL((k_rollout_gru_lockstep<CartPoleLs64, false, 4>), dim3(blocks), dim3(256), 0, h->stream,
                                    theta, init, init_per_offspring, n_rows, E, h->P, T, h->obs_mask, epr, ep_steps);
         } else if (pick_lanes_per_env(h, (long long)episodes) >= 8) {
             const int blocks = ceil_div((long long)episodes * 8, 64);
@@ -1037,11 +1041,11 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
     } else if (h->cfg.gru && !gru_sequential()) {
         const int blocks = ceil_div(n_rows, 4);
         if (mode == SES_MODE_FIXED_LENGTH)
-            hipLaunchKernelGGL((k_rollout_gru_lockstep<CartPoleLs, true>), dim3(blocks), dim3(256), 0, h->stream, theta,
+            hipLaunchKernelGGL((k_rollout_gru_lockstep<CartPoleLs, true, 4>), dim3(blocks), dim3(256), 0, h->stream, theta,
                                init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
                                epr, ep_steps);
         else
-            hipLaunchKernelGGL((k_rollout_gru_lockstep<CartPoleLs, false>), dim3(blocks), dim3(256), 0, h->stream, theta,
+            hipLaunchKernelGGL((k_rollout_gru_lockstep<CartPoleLs, false, 4>), dim3(blocks), dim3(256), 0, h->stream, theta,
                                init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
                                epr, ep_steps);
     } else if (h->cfg.gru) {

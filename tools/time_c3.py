@@ -27,5 +27,8 @@ def run(name, gru, pomdp, n, sigma, reps=3):
     es.close()
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-run("C3 LunarLanderContinuous-v2 POMDP GRU", True, True, n, 0.168)
-run("LunarLanderContinuous-v2 MLP", False, False, n, 2.0)
+which = sys.argv[2] if len(sys.argv) > 2 else "both"
+if which in ("both", "gru"):
+    run("C3 LunarLanderContinuous-v2 POMDP GRU", True, True, n, 0.168)
+if which in ("both", "mlp"):
+    run("LunarLanderContinuous-v2 MLP", False, False, n, 2.0)
