@@ -46,11 +46,15 @@ extern "C" {
 /* env_id */
 #define SES_ENV_NONE (-1)  /* no env: handle only serves policy-forward / strategy kernels */
 #define SES_ENV_CARTPOLE 0 /* CartPole-v1 via envs/gym_wrapper.py:7-54 (conf/cartpole.yaml) */
-#define SES_ENV_LUNARLANDER 1 /* LunarLanderContinuous-v2 via envs/gym_wrapper.py (conf/lunarlander_openai.yaml): a REDUCED   */
-                              /* rigid-body lander ("lite", csrc/ses_lander.h); num_state 8, num_action 4, continuous;      */
+#define SES_ENV_LUNARLANDER 1 /* LunarLanderContinuous-v2 via envs/gym_wrapper.py (conf/lunarlander_openai.yaml): gym's env     */
+                              /* restated on a Box2D-style world (csrc/ses_lander.h, ses_b2.h; parity with gym / Box2D is   */
+                              /* UNPINNED, neither is in the reference tree); num_state 8, num_action 4, continuous;        */
                               /* pomdp zeroes obs 2,3,5 (LunarLanderPOMDP, gym_wrapper.py:57-66); init rows: 16 uniforms   */
 #define SES_ENV_SIMPLE_SPREAD 2 /* pettingzoo MPE simple_spread via envs/pettingzoo_wrapper.py:6-64 (conf/simplespread.yaml); */
                                 /* num_state = 6*n_agents, num_action = 5, discrete, MLP policy shared by the agents      */
+#define SES_ENV_BIPEDALWALKER 3 /* BipedalWalker-v3 via envs/gym_wrapper.py (conf/bipedalwalker.yaml): gym's env restated on   */
+                                /* the same Box2D-style world (csrc/ses_walker.h; parity UNPINNED); num_state 24, num_action  */
+                                /* 4, continuous, MLP policy; init rows: 4 floats (force uniform, 2 terrain-key words, pad)   */
 
 /* rollout / env-step mode */
 #define SES_MODE_EPISODIC 0     /* an env stops at done (reference semantics, loop.py:116)      */

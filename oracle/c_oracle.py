@@ -200,3 +200,47 @@ class LanderSim:
         done = ctypes.c_int32(0)
         r = lib().o_lander_step(self._buf, ctypes.c_float(a0), ctypes.c_float(a1), _p(obs), ctypes.byref(done))
         return obs, float(r), bool(done.value)
+
+
+def rollout_walker(theta, init, E, max_step=300, *, gru=False):
+    """BipedalWalker-v3 population rollout (ses_walker_env.h over the Box2D-style world of ses_b2.h).
+    init: [E, 4] or [N, E, 4] rows (force uniform, terrain key words, pad).  Returns (fitness, ep_return f64, ep_steps)."""
+    theta = np.atleast_2d(_f32(theta))
+    N = theta.shape[0]
+    init = _f32(init)
+    per = 1 if init.ndim == 3 else 0
+    assert init.shape[-2:] == (E, 4), init.shape
+    ep_ret = np.empty((N, E), dtype=np.float64)
+    ep_steps = np.empty((N, E), dtype=np.int32)
+    fit = np.empty(N, dtype=np.float32)
+    lib().o_rollout_walker(ctypes.c_int(int(gru)), ctypes.c_int(N), ctypes.c_int(E), ctypes.c_int(max_step),
+                           _p(theta), _p(init), ctypes.c_int(per), _p(ep_ret), _p(ep_steps), _p(fit))
+    return fit, ep_ret, ep_steps
+
+
+class WalkerSim:
+    """one BipedalWalker-v3 env driven step by step"""
+
+    def __init__(self):
+        self._buf = ctypes.create_string_buffer(lib().o_walker_state_size())
+        lib().o_walker_step.restype = ctypes.c_float
+
+    def reset(self, u4):
+        u4 = _f32(u4)
+        obs = np.empty(24, dtype=np.float32)
+        lib().o_walker_reset(self._buf, _p(u4), _p(obs))
+        return obs
+
+    def step(self, action):
+        a = _f32(np.asarray(action).reshape(4))
+        obs = np.empty(24, dtype=np.float32)
+        done = ctypes.c_int32(0)
+        r = lib().o_walker_step(self._buf, _p(a), _p(obs), ctypes.byref(done))
+        return obs, float(r), bool(done.value)
+
+    def debug(self):
+        bodies = np.empty((5, 6), dtype=np.float32)
+        terrain = np.empty(200, dtype=np.float32)
+        ints = np.zeros(6, dtype=np.int32)
+        lib().o_walker_debug(self._buf, _p(bodies), _p(terrain), _p(ints))
+        return bodies, terrain, {"game_over": int(ints[0]), "contact_points": int(ints[1]), "limits": ints[2:6].tolist()}

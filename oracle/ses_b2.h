@@ -118,7 +118,7 @@ struct World {
     Body body[D::NB];
     Xf xf[D::NB];                    // transforms at the start of the current step (Collide / solver initialisation)
     Joint joint[D::NJ];
-    Manifold mf[D::NB][D::NSLOT];
+    Manifold mf[D::NB - D::FIRST_SOLVED][D::NSLOT];   // of the bodies whose contacts are solved (index b - FIRST_SOLVED)
     float sleep_time[D::NB];
     bool ground_contact[D::NB];
     bool game_over, awake, first_step;
@@ -337,10 +337,23 @@ B2_FN void collide(World<D> &w, const T &terr)
         int k_lo = terr.index_of(xmin - AABB_EXTENSION), k_hi = terr.index_of(xmax + AABB_EXTENSION);
         k_lo = k_lo < 0 ? 0 : k_lo;
         k_hi = k_hi > terr.n_edges() - 1 ? terr.n_edges() - 1 : k_hi;
+        if (b < D::FIRST_SOLVED) {
+            // the hull: touching the terrain ends the episode (the envs' contact listeners), nothing is solved or kept
+            for (int k = k_lo; k <= k_hi; ++k) {
+                float x1, y1, x2, y2;
+                terr.edge(k, x1, y1, x2, y2);
+                if (!(ymin - AABB_EXTENSION > b2max(y1, y2))) {
+                    Manifold tmp;
+                    collide_edge_polygon(P, xf, wx, wy, wnx, wny, ccx, ccy, x1, y1, x2, y2, tmp);
+                    if (tmp.count > 0) w.game_over = true;
+                }
+            }
+            continue;
+        }
         k_hi = k_hi > k_lo + D::NSLOT - 1 ? k_lo + D::NSLOT - 1 : k_hi;
         B2_UNROLL
         for (int s = 0; s < D::NSLOT; ++s) {
-            Manifold &m = w.mf[b][s];
+            Manifold &m = w.mf[b - D::FIRST_SOLVED][s];
             const int k = k_lo + ((s - k_lo) & (D::NSLOT - 1));       // the candidate edge that maps to this slot
             const bool candidate = k <= k_hi && k_lo <= k_hi;
             const bool was_touching = m.edge >= 0 && m.count > 0;
@@ -369,10 +382,7 @@ B2_FN void collide(World<D> &w, const T &terr)
             }
             const bool still = same_edge && was_touching;
             if (was_touching && !(still && m.count > 0)) w.ground_contact[b] = false;          // EndContact
-            if (m.count > 0 && !still) {                                                       // BeginContact
-                w.ground_contact[b] = true;
-                if (b < D::FIRST_SOLVED) w.game_over = true;
-            }
+            if (m.count > 0 && !still) w.ground_contact[b] = true;                             // BeginContact
         }
     }
 }
@@ -737,14 +747,14 @@ B2_FN void world_step(World<D> &w, const T &terr, float dt)
     for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
         B2_UNROLL
         for (int s = 0; s < D::NSLOT; ++s) {
-            contact_init(w.mf[b][s], ct[b - D::FIRST_SOLVED][s], w.body[b], D::body()[b], w.xf[b]);
-            any_contact = any_contact || w.mf[b][s].count > 0;
+            contact_init(w.mf[b - D::FIRST_SOLVED][s], ct[b - D::FIRST_SOLVED][s], w.body[b], D::body()[b], w.xf[b]);
+            any_contact = any_contact || w.mf[b - D::FIRST_SOLVED][s].count > 0;
         }
     }
     B2_UNROLL
     for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
         B2_UNROLL
-        for (int s = 0; s < D::NSLOT; ++s) contact_warm_start(w.mf[b][s], ct[b - D::FIRST_SOLVED][s], w.body[b], D::body()[b]);
+        for (int s = 0; s < D::NSLOT; ++s) contact_warm_start(w.mf[b - D::FIRST_SOLVED][s], ct[b - D::FIRST_SOLVED][s], w.body[b], D::body()[b]);
     }
     B2_UNROLL
     for (int j = 0; j < D::NJ; ++j) joint_init(w, j, jt[j], dt);
@@ -759,7 +769,7 @@ B2_FN void world_step(World<D> &w, const T &terr, float dt)
             for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
                 B2_UNROLL
                 for (int s = 0; s < D::NSLOT; ++s)
-                    contact_solve_velocity(w.mf[b][s], ct[b - D::FIRST_SOLVED][s], w.body[b], D::body()[b]);
+                    contact_solve_velocity(w.mf[b - D::FIRST_SOLVED][s], ct[b - D::FIRST_SOLVED][s], w.body[b], D::body()[b]);
             }
         }
     }
@@ -792,7 +802,7 @@ B2_FN void world_step(World<D> &w, const T &terr, float dt)
                 for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
                     B2_UNROLL
                     for (int s = 0; s < D::NSLOT; ++s)
-                        min_separation = b2min(min_separation, contact_solve_position(w.mf[b][s], w.body[b], D::body()[b]));
+                        min_separation = b2min(min_separation, contact_solve_position(w.mf[b - D::FIRST_SOLVED][s], w.body[b], D::body()[b]));
                 }
             }
             const bool contacts_okay = min_separation >= -3.0f * LINEAR_SLOP;

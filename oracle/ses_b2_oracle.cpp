@@ -31,8 +31,20 @@ static inline void b2o_dispersion(uint32_t key0, uint32_t key1, int step, float 
     *d1 = o_fma(b2o_u32_to_unit(r[1]), 2.0f, -1.0f);
 }
 #define B2_DISPERSION(k0, k1, step, d0, d1) b2o_dispersion((k0), (k1), (step), &(d0), &(d1))
+// BipedalWalker terrain randomness for point i: the same Philox call as the device
+// (ses_rng.h philox_words(seed, TAG_ENV_TERRAIN, 0, 0, i)): word 0 -> uniform in (-1, 1), word 1 raw
+static inline void b2o_terrain_rand(uint32_t key0, uint32_t key1, int i, float *u, uint32_t *r)
+{
+    const uint32_t ctr[4] = {(uint32_t)i, 0u, 0u, (uint32_t)(3ull << 24)}, key[2] = {key0, key1};
+    uint32_t w[4];
+    o_philox_raw(ctr, key, w);
+    *u = o_fma(b2o_u32_to_unit(w[0]), 2.0f, -1.0f);
+    *r = w[1];
+}
+#define B2_TERRAIN_RAND(k0, k1, i, u, r) b2o_terrain_rand((k0), (k1), (i), &(u), &(r))
 
 #include "ses_lander_env.h"
+#include "ses_walker_env.h"
 
 using namespace b2l;
 
@@ -91,8 +103,64 @@ void o_lander_debug(const void *state, float *bodies, int32_t *ints)
     ints[6] = s->env.w.ground_contact[2];
     int touching = 0;
     for (int b = 0; b < 3; ++b)
-        for (int k = 0; k < 2; ++k) touching += s->env.w.mf[b][k].count;
+        for (int k = 0; k < 2; ++k) touching += b >= 1 ? s->env.w.mf[b - 1][k].count : 0;
     ints[7] = touching;
+}
+
+// ---- BipedalWalker-v3 ----
+struct WalkerSim {
+    WalkerEnv env;
+    float ty[BW_TERRAIN_LENGTH];
+};
+
+int o_walker_state_size(void) { return (int)sizeof(WalkerSim); }
+
+void o_walker_obs(const void *state, float *obs)
+{
+    float o[24];
+    walker_obs(((const WalkerSim *)state)->env, o);
+    memcpy(obs, o, sizeof o);
+}
+
+// init row: [0] initial-force uniform, [1], [2] the bit patterns of the terrain key, [3] unused
+void o_walker_reset(void *state, const float *u4, float *obs)
+{
+    WalkerSim *s = (WalkerSim *)state;
+    memset(s, 0, sizeof *s);
+    walker_terrain_heights(o_f2u(u4[1]), o_f2u(u4[2]), s->ty);
+    WalkerTerrain terr{s->ty};
+    walker_reset(s->env, terr, u4);
+    if (obs) o_walker_obs(state, obs);
+}
+
+float o_walker_step(void *state, const float *action4, float *obs, int32_t *done)
+{
+    WalkerSim *s = (WalkerSim *)state;
+    WalkerTerrain terr{s->ty};
+    const float a[4] = {action4[0], action4[1], action4[2], action4[3]};
+    bool d;
+    const float r = walker_step(s->env, terr, a, d);
+    if (obs) o_walker_obs(state, obs);
+    *done = d ? 1 : 0;
+    return r;
+}
+
+// diagnostics for the tests: bodies [5][6] (c, a, v, w), terrain [200], flags {game_over, contact points, limit states x4}
+void o_walker_debug(const void *state, float *bodies, float *terrain, int32_t *ints)
+{
+    const WalkerSim *s = (const WalkerSim *)state;
+    for (int b = 0; b < 5; ++b) {
+        const Body &B = s->env.w.body[b];
+        const float v[6] = {B.cx, B.cy, B.a, B.vx, B.vy, B.w};
+        memcpy(bodies + 6 * b, v, sizeof v);
+    }
+    memcpy(terrain, s->ty, sizeof s->ty);
+    ints[0] = s->env.w.game_over;
+    int touching = 0;
+    for (int b = 0; b < 4; ++b)
+        for (int k = 0; k < 4; ++k) touching += s->env.w.mf[b][k].count;
+    ints[1] = touching;
+    for (int j = 0; j < 4; ++j) ints[2 + j] = s->env.w.joint[j].state;
 }
 
 }  // extern "C"

@@ -168,8 +168,8 @@ B2_FN void lander_reset_state(LanderEnv &e, const float *u)
         w.sleep_time[b] = 0.0f;
         w.ground_contact[b] = false;
         B2_UNROLL
-        for (int s = 0; s < LanderDef::NSLOT; ++s) {
-            Manifold &m = w.mf[b][s];
+        for (int s = 0; s < LanderDef::NSLOT && b >= LanderDef::FIRST_SOLVED; ++s) {
+            Manifold &m = w.mf[b - LanderDef::FIRST_SOLVED][s];
             m.edge = -1; m.count = 0; m.type = 0;
             m.lnx = 0.0f; m.lny = 0.0f; m.lpx = 0.0f; m.lpy = 0.0f;
             B2_UNROLL

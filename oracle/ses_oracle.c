@@ -625,3 +625,44 @@ void o_rollout_lander(int gru, int N, int E, int max_step, uint32_t obs_mask, co
     }
     free(st);
 }
+
+/* ========================================================================================== */
+/* BipedalWalker-v3 (conf/bipedalwalker.yaml of the reference: MLP policy, 24 observations, 4 tanh outputs = the four
+ * joint motors).  The env -- gym's bipedal_walker.py on a Box2D world of five bodies and four revolute joints -- is
+ * restated in ses_b2.h / ses_walker_env.h (C++, ses_b2_oracle.cpp); parity with gym / Box2D is UNPINNED (see there).
+ * One initial-state row = 4 floats: [0] uniform of the initial hull force, [1], [2] bit patterns of the key of the
+ * episode's terrain stream, [3] unused. */
+int o_walker_state_size(void);
+void o_walker_reset(void *state, const float *u4, float *obs);
+float o_walker_step(void *state, const float *action4, float *obs, int32_t *done);
+
+void o_rollout_walker(int gru, int N, int E, int max_step, const float *theta, const float *init,
+                      int init_per_offspring, double *ep_return, int32_t *ep_steps, float *fitness)
+{
+    const int S = 24, A = 4;
+    const int P = o_param_count(S, A, gru);
+    void *st = malloc((size_t)o_walker_state_size());
+    for (int i = 0; i < N; ++i) {
+        net_view v = view_params(theta + (size_t)i * P, S, A, gru);
+        double total = 0.0;
+        for (int e = 0; e < E; ++e) {
+            float obs[24];
+            o_walker_reset(st, init + ((size_t)(init_per_offspring ? i : 0) * E + e) * 4, obs);
+            float h[SES_H] = {0};
+            double ret = 0.0;
+            int steps = 0;
+            int32_t done = 0;
+            while (!done && steps < max_step) {
+                float logits[SES_MAX_A], act[SES_MAX_A];
+                (void)policy_forward(&v, S, A, 0, gru, obs, h, logits, act);
+                ret += (double)o_walker_step(st, act, obs, &done);
+                steps += 1;
+            }
+            ep_return[(size_t)i * E + e] = ret;
+            if (ep_steps) ep_steps[(size_t)i * E + e] = steps;
+            total += ret;
+        }
+        fitness[i] = (float)(total / (double)E);
+    }
+    free(st);
+}

@@ -75,7 +75,7 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
 {
     SES_REQUIRE(cfg && out, "ses_create: null argument");
     SES_REQUIRE(cfg->env_id == SES_ENV_CARTPOLE || cfg->env_id == SES_ENV_NONE || cfg->env_id == SES_ENV_SIMPLE_SPREAD ||
-                    cfg->env_id == SES_ENV_LUNARLANDER,
+                    cfg->env_id == SES_ENV_LUNARLANDER || cfg->env_id == SES_ENV_BIPEDALWALKER,
                 "ses_create: unknown env_id %d", cfg->env_id);
     SES_REQUIRE(cfg->num_state >= 1 && cfg->num_state <= 32, "ses_create: num_state %d out of range", cfg->num_state);
     SES_REQUIRE(cfg->num_action >= 1 && cfg->num_action <= 8, "ses_create: num_action %d out of range", cfg->num_action);
@@ -90,6 +90,9 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     if (cfg->env_id == SES_ENV_LUNARLANDER)
         SES_REQUIRE(cfg->num_state == 8 && cfg->num_action == 4 && !cfg->discrete_action,
                     "ses_create: LunarLanderContinuous needs num_state=8 num_action=4 discrete_action=0");
+    if (cfg->env_id == SES_ENV_BIPEDALWALKER)
+        SES_REQUIRE(cfg->num_state == 24 && cfg->num_action == 4 && !cfg->discrete_action && !cfg->gru && !cfg->pomdp,
+                    "ses_create: BipedalWalker needs num_state=24 num_action=4 discrete_action=0 gru=0 pomdp=0");
     if (cfg->env_id == SES_ENV_SIMPLE_SPREAD)
         SES_REQUIRE((cfg->n_agents == 2 || cfg->n_agents == 3) && cfg->num_state == 6 * cfg->n_agents &&
                         cfg->num_action == 5 && cfg->discrete_action && !cfg->gru,

@@ -10,6 +10,7 @@
 #include "ses_gru_lockstep.h"
 #include "ses_gru_mfma.h"
 #include "ses_lander.h"
+#include "ses_walker.h"
 #include "ses_internal.h"
 #include "ses_policy.h"
 #include "ses_spread.h"
@@ -544,23 +545,21 @@ __global__ __launch_bounds__(256, 2) void k_rollout_gru_mfma(const float *__rest
 }
 
 // LunarLanderContinuous-v2 (ses_lander.h): continuous control (tanh head, the env uses outputs 0 and 1 -- SURVEY 3.4-12), float
-// rewards accumulated in float64 like the reference's python sum (loop.py:123).  GRU: one offspring per wave
-// (the env is wave-uniform, so contact iterations are skipped by scalar branches while the lander is in
-// flight); MLP: 8 lanes per env.
-template <bool GRU>
-__global__ __launch_bounds__(256, 2) void k_rollout_lander(const float *__restrict__ theta,
+// rewards accumulated in float64 like the reference's python sum (loop.py:123).  GRU policy, one offspring (or one
+// episode of it, ep_parallel) per wave, episodes one after the other; the MLP policies run in k_rollout_box2d_mlp.
+__global__ __launch_bounds__(256, 2) void k_rollout_lander_gru(const float *__restrict__ theta,
                                                         const float *__restrict__ init, int init_per_offspring,
                                                         int n_rows, int E, int P, int max_step, uint32_t obs_mask,
                                                         double *__restrict__ ep_return, int32_t *__restrict__ ep_steps,
                                                         int ep_parallel)
 {
-    constexpr int S = 8, A = 4, LPE = 8;
+    constexpr int S = 8, A = 4;
     __shared__ TanhEntry tanh_tab[SES_TANH_N];
     __shared__ __attribute__((aligned(16))) float vecs[4][64];
-    __shared__ float terrain[256 / LPE][LL_TERRAIN_ROW];          // terrain rows: GRU one per wave, MLP one per env
+    __shared__ float terrain[4][LL_TERRAIN_ROW];                  // one terrain row per wave
     stage_tanh_table(tanh_tab);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if constexpr (GRU) {
+    {
         const int unit = blockIdx.x * 4 + wave, n_units = ep_parallel ? n_rows * E : n_rows;   // see k_rollout_cartpole_gru
         const bool valid = unit < n_units;
         const int u = valid ? unit : n_units - 1;
@@ -595,41 +594,74 @@ __global__ __launch_bounds__(256, 2) void k_rollout_lander(const float *__restri
                 if (ep_steps) ep_steps[(size_t)row * E + ep] = steps;
             }
         }
-    } else {
-        const long long gtid = (long long)blockIdx.x * 256 + threadIdx.x;
-        const int n_env = n_rows * E;
-        int env = (int)(gtid / LPE);
-        const int sub = (int)(threadIdx.x % LPE);
-        const bool valid = env < n_env;
-        env = valid ? env : n_env - 1;
-        const int row = env / E, ep = env - row * E;
-        MlpSlice<S, A, LPE> net;
+    }
+}
+
+// MLP policies on the Box2D-style envs (LunarLander: conf/lunarlander.yaml, BipedalWalker: conf/bipedalwalker.yaml):
+// 8 lanes per env (4 hidden units each) for the forward, every lane of a group carries the env.  EnvB adapts an env.
+struct LanderMlpEnv {
+    static constexpr int S = 8, A = 4, INIT_W = 16, ROW = LL_TERRAIN_ROW;
+    using State = LanderState;
+    __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u, float *row) { ll_reset(s, u, row); }
+    __device__ static __forceinline__ void observe(const State &s, float (&obs)[S]) { ll_obs(s, obs); }
+    __device__ static __forceinline__ float step(State &s, const float (&act)[A], bool &done) { return ll_step(s, act[0], act[1], done); }
+};
+
+struct WalkerMlpEnv {
+    static constexpr int S = 24, A = 4, INIT_W = 4, ROW = BW_TERRAIN_ROW;
+    using State = WalkerState;
+    __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u, float *row) { bw_reset(s, u, row); }
+    __device__ static __forceinline__ void observe(const State &s, float (&obs)[S]) { bw_obs(s, obs); }
+    __device__ static __forceinline__ float step(State &s, const float (&act)[A], bool &done)
+    {
+        return bw_step(s, act[0], act[1], act[2], act[3], done);
+    }
+};
+
+template <class EnvB>
+__global__ __launch_bounds__(256, 2) void k_rollout_box2d_mlp(const float *__restrict__ theta,
+                                                           const float *__restrict__ init, int init_per_offspring,
+                                                           int n_rows, int E, int P, int max_step, uint32_t obs_mask,
+                                                           double *__restrict__ ep_return,
+                                                           int32_t *__restrict__ ep_steps)
+{
+    constexpr int S = EnvB::S, A = EnvB::A, LPE = 8;
+    __shared__ TanhEntry tanh_tab[SES_TANH_N];
+    __shared__ float terrain[256 / LPE][EnvB::ROW];               // one terrain row per env
+    stage_tanh_table(tanh_tab);
+    const long long gtid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int n_env = n_rows * E;
+    int env = (int)(gtid / LPE);
+    const int sub = (int)(threadIdx.x % LPE);
+    const bool valid = env < n_env;
+    env = valid ? env : n_env - 1;
+    const int row = env / E, ep = env - row * E;
+    MlpSlice<S, A, LPE> net;
+    typename EnvB::State st;
+    EnvB::reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * EnvB::INIT_W, terrain[threadIdx.x / LPE]);
+    double ret = 0.0;
+    int steps = 0;
+    bool done = false;
+    for (int t = 0; t < max_step; ++t) {
+        if (__ballot(!done) == 0ull) break;
+        // the lane's weight slice is re-read from the (L2-resident) row every step: a few dozen loads next to a
+        // 20 000-instruction world step, and nothing of the policy has to stay in registers across it
         net.load(theta + (size_t)row * P, sub);
-        LanderState st;
-        ll_reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 16, terrain[threadIdx.x / LPE]);
-        double ret = 0.0;
-        int steps = 0;
-        bool done = false;
-        for (int t = 0; t < max_step; ++t) {
-            if (__ballot(!done) == 0ull) break;
-            // the lane's weight slice is re-read from the (L2-resident) row every step: 56 loads next to a 36 k
-            // instruction world step, and nothing of the policy has to stay in registers across it
-            net.load(theta + (size_t)row * P, sub);
-            float obs[S], logits[A];
-            ll_obs(st, obs);
+        float obs[S], logits[A], act[A];
+        EnvB::observe(st, obs);
 #pragma unroll
-            for (int k = 0; k < S; ++k) obs[k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
-            net.forward(tanh_tab, obs, logits);
-            const float a0 = tanh_(tanh_tab, logits[0]), a1 = tanh_(tanh_tab, logits[1]);
-            if (!done) {                                           // a finished env is frozen
-                ret += (double)ll_step(st, a0, a1, done);
-                steps += 1;
-            }
+        for (int k = 0; k < S; ++k) obs[k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
+        net.forward(tanh_tab, obs, logits);
+#pragma unroll
+        for (int k = 0; k < A; ++k) act[k] = tanh_(tanh_tab, logits[k]);
+        if (!done) {                                               // a finished env is frozen
+            ret += (double)EnvB::step(st, act, done);
+            steps += 1;
         }
-        if (valid && sub == 0) {
-            ep_return[env] = ret;
-            if (ep_steps) ep_steps[env] = steps;
-        }
+    }
+    if (valid && sub == 0) {
+        ep_return[env] = ret;
+        if (ep_steps) ep_steps[env] = steps;
     }
 }
 
@@ -947,7 +979,7 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
     SES_REQUIRE(mode == SES_MODE_EPISODIC || mode == SES_MODE_FIXED_LENGTH, "ses_rollout: bad mode %d", mode);
     SES_REQUIRE((long long)n_rows * h->cfg.eval_ep_num * 8 < (1ll << 31), "ses_rollout: shard too large");
     SES_REQUIRE(h->cfg.env_id == SES_ENV_CARTPOLE || h->cfg.env_id == SES_ENV_SIMPLE_SPREAD ||
-                    h->cfg.env_id == SES_ENV_LUNARLANDER,
+                    h->cfg.env_id == SES_ENV_LUNARLANDER || h->cfg.env_id == SES_ENV_BIPEDALWALKER,
                 "ses_rollout: handle has no env");
     SES_HIP_TRY(hipSetDevice(h->cfg.device));
     const size_t episodes = (size_t)n_rows * h->cfg.eval_ep_num;
@@ -961,7 +993,7 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
         SES_REQUIRE(mode == SES_MODE_EPISODIC, "ses_rollout: LunarLander has no fixed-length mode");
         const bool epp = h->cfg.gru && !gru_sequential() && gru_episode_parallel(h, (long long)episodes);
         if (epp)
-            hipLaunchKernelGGL((k_rollout_lander<true>), dim3(ceil_div((long long)episodes, 4)), dim3(256), 0, h->stream,
+            hipLaunchKernelGGL(k_rollout_lander_gru, dim3(ceil_div((long long)episodes, 4)), dim3(256), 0, h->stream,
                                theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step,
                                h->obs_mask, epr, ep_steps, 1);
         else if (h->cfg.gru && !gru_sequential() && h->cfg.eval_ep_num >= gru_mfma_min_e())
@@ -973,13 +1005,19 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
                                h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
                                h->cfg.max_step, h->obs_mask, epr, ep_steps);
         else if (h->cfg.gru)
-            hipLaunchKernelGGL((k_rollout_lander<true>), dim3(ceil_div(n_rows, 4)), dim3(256), 0, h->stream, theta, init,
+            hipLaunchKernelGGL(k_rollout_lander_gru, dim3(ceil_div(n_rows, 4)), dim3(256), 0, h->stream, theta, init,
                                init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, epr,
                                ep_steps, 0);
         else
-            hipLaunchKernelGGL((k_rollout_lander<false>), dim3(ceil_div((long long)episodes * 8, 256)), dim3(256), 0,
+            hipLaunchKernelGGL((k_rollout_box2d_mlp<LanderMlpEnv>), dim3(ceil_div((long long)episodes * 8, 256)), dim3(256), 0,
                                h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
-                               h->cfg.max_step, h->obs_mask, epr, ep_steps, 0);
+                               h->cfg.max_step, h->obs_mask, epr, ep_steps);
+    } else if (h->cfg.env_id == SES_ENV_BIPEDALWALKER) {
+        SES_REQUIRE(mode == SES_MODE_EPISODIC, "ses_rollout: BipedalWalker has no fixed-length mode");
+        SES_REQUIRE(!h->cfg.gru, "ses_rollout: BipedalWalker has an MLP-policy kernel only (conf/bipedalwalker.yaml: gru False)");
+        hipLaunchKernelGGL((k_rollout_box2d_mlp<WalkerMlpEnv>), dim3(ceil_div((long long)episodes * 8, 256)), dim3(256), 0,
+                           h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
+                           h->cfg.max_step, h->obs_mask, epr, ep_steps);
     } else if (h->cfg.env_id == SES_ENV_SIMPLE_SPREAD) {
         SES_REQUIRE(ep_steps == nullptr, "ses_rollout: simple_spread episodes have a fixed length, no ep_steps");
         const int blocks = ceil_div((long long)episodes * 8, 64);
@@ -1141,6 +1179,7 @@ int ses_policy_forward(ses_handle *h, const float *theta, const float *obs, floa
     SES_FWD_CASE(8, 4)
     SES_FWD_CASE(12, 5)
     SES_FWD_CASE(18, 5)
+    SES_FWD_CASE(24, 4)
 #undef SES_FWD_CASE
     return set_error(SES_ERR_UNSUPPORTED, "ses_policy_forward: no kernel instance for num_state=%d num_action=%d", S, A);
 }

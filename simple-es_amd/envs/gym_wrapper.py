@@ -11,7 +11,9 @@ import torch
 SUPPORTED = {"CartPole-v1": dict(num_state=4, num_action=2, discrete=True, time_limit=500),
              "CartPole-v0": dict(num_state=4, num_action=2, discrete=True, time_limit=200),
              # gym's env restated on a Box2D-style world (csrc/ses_lander.h, ses_b2.h) -- gym's own TimeLimit is 1000 steps
-             "LunarLanderContinuous-v2": dict(num_state=8, num_action=4, discrete=False, time_limit=1000)}
+             "LunarLanderContinuous-v2": dict(num_state=8, num_action=4, discrete=False, time_limit=1000),
+             # gym's env restated on the same world (csrc/ses_walker.h) -- gym's TimeLimit is 1600 steps
+             "BipedalWalker-v3": dict(num_state=24, num_action=4, discrete=False, time_limit=1600)}
 
 
 class GymWrapper:
@@ -30,7 +32,7 @@ class GymWrapper:
         self.spec = SUPPORTED[name]
         # a gym name whose third-party physics is restated here without a pin says so at run time (ESLoop prints it,
         # metrics.jsonl records it): returns are the build's own, not gym + Box2D's bit for bit
-        self.variant = "box2d-restated" if "LunarLander" in name else None
+        self.variant = "box2d-restated" if ("LunarLander" in name or "BipedalWalker" in name) else None
         # YAML `max_step: None` is the STRING "None" in the reference (gym_wrapper.py:37); accept both.
         limit = self.spec["time_limit"]
         self.max_step = max_step

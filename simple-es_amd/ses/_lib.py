@@ -14,6 +14,7 @@ ENV_NONE = -1
 ENV_CARTPOLE = 0
 ENV_LUNARLANDER = 1
 ENV_SIMPLE_SPREAD = 2
+ENV_BIPEDALWALKER = 3
 MODE_EPISODIC = 0
 MODE_FIXED_LENGTH = 1
 HIDDEN = 32

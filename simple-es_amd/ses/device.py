@@ -10,10 +10,11 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ENV_CARTPOLE, ENV_LUNARLANDER, ENV_NONE, ENV_SIMPLE_SPREAD, HIDDEN, MODE_EPISODIC, SesConfig, SesError, check
+from ._lib import (ENV_BIPEDALWALKER, ENV_CARTPOLE, ENV_LUNARLANDER, ENV_NONE, ENV_SIMPLE_SPREAD, HIDDEN, MODE_EPISODIC,
+                   SesConfig, SesError, check)
 
 ENV_IDS = {"CartPole-v1": ENV_CARTPOLE, "CartPole-v0": ENV_CARTPOLE, "simple_spread": ENV_SIMPLE_SPREAD,
-           "LunarLanderContinuous-v2": ENV_LUNARLANDER, None: ENV_NONE}
+           "LunarLanderContinuous-v2": ENV_LUNARLANDER, "BipedalWalker-v3": ENV_BIPEDALWALKER, None: ENV_NONE}
 
 
 def param_count(num_state, num_action, gru):
@@ -50,6 +51,8 @@ class HipES:
             self.init_dim, self.init_range = 4 * self.n_agents, (-1.0, 1.0)
         elif self.env_id == ENV_LUNARLANDER:
             self.init_dim, self.init_range = 16, (0.0, 1.0)      # force, terrain heights, noise key (csrc/ses_lander.h)
+        elif self.env_id == ENV_BIPEDALWALKER:
+            self.init_dim, self.init_range = 4, (0.0, 1.0)       # force uniform, terrain key (2 words), pad (csrc/ses_walker.h)
         else:
             self.init_dim, self.init_range = 4, (-0.05, 0.05)
         cfg = SesConfig(self.env_id, self.S, self.A, int(self.discrete), int(self.gru), int(self.pomdp),

@@ -1,0 +1,76 @@
+"""BipedalWalker-v3 on the CPU (oracle/ses_walker_env.h over the Box2D-style world of oracle/ses_b2.h): behavioural
+checks -- gym and Box2D are not here to compare with (parity unpinned, see the headers)."""
+import filecmp
+import os
+
+import numpy as np
+
+from oracle import c_oracle as co
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_walker_header_is_one_text_in_oracle_and_product():
+    assert filecmp.cmp(os.path.join(ROOT, "oracle", "ses_walker_env.h"),
+                       os.path.join(ROOT, "simple-es_amd", "csrc", "ses_walker_env.h"), shallow=False)
+
+
+def test_terrain_is_gyms_random_walk():
+    sim = co.WalkerSim()
+    sim.reset(np.array([0.5, 0.123, 0.456, 0.0], np.float32))
+    _, terr, _ = sim.debug()
+    th = 400 / 30 / 4
+    assert np.allclose(terr[:21], th)                              # TERRAIN_STARTPAD: flat start
+    assert np.abs(np.diff(terr)).max() < 0.2 and abs(terr.mean() - th) < 0.5
+    assert np.unique(terr[21:]).size > 120                         # a random walk with a flat repeat every 5..9 points
+    sim.reset(np.array([0.5, 0.124, 0.456, 0.0], np.float32))
+    assert not np.array_equal(sim.debug()[1], terr)                # keyed by the init row
+
+
+def _run(sim, u, ctrl, limit=300):
+    obs = sim.reset(u)
+    tot, t, done = 0.0, 0, False
+    while not done and t < limit:
+        obs, r, done = sim.step(ctrl(obs, t))
+        tot += r
+        t += 1
+    return tot, t, obs
+
+
+def test_walker_behaves_like_gyms():
+    rng = np.random.RandomState(0)
+    sim = co.WalkerSim()
+    obs = sim.reset(rng.rand(4).astype(np.float32))
+    assert obs.shape == (24,) and abs(obs[0]) < 0.05               # upright hull after reset
+    lidar = obs[14:]
+    assert np.all(np.diff(lidar[:8]) > 0) and lidar[0] > 0.3 and lidar[9] == 1.0   # rays fan out from straight down
+    # no torque: the legs fold, the hull hits the ground: -100 (gym: same, after ~100 steps)
+    tot, t, _ = _run(sim, rng.rand(4).astype(np.float32), lambda o, k: np.zeros(4))
+    assert tot < -95 and 50 < t < 200
+    # random torques: falls as well
+    r = [_run(sim, rng.rand(4).astype(np.float32), lambda o, k: rng.uniform(-1, 1, 4))[0] for _ in range(5)]
+    assert np.mean(r) < -80
+    # joints hold: hip and knee anchors coincide to Box2D's tolerances while the walker stands / falls
+    sim.reset(rng.rand(4).astype(np.float32))
+    lh = 34 / 30
+    worst = 0.0
+    for k in range(60):
+        sim.step(np.array([0.3, -0.3, -0.3, 0.3]))
+        b, _, info = sim.debug()
+        for up, lo in ((1, 2), (3, 4)):
+            pu = b[up][:2] + np.array([np.sin(b[up][2]) * lh / 2, -np.cos(b[up][2]) * lh / 2])     # upper leg's lower end
+            pl = b[lo][:2] + np.array([-np.sin(b[lo][2]) * lh / 2, np.cos(b[lo][2]) * lh / 2])     # lower leg's upper end
+            worst = max(worst, float(np.hypot(*(pu - pl))))
+    assert worst < 0.03, worst
+
+
+def test_population_rollout_entry_point():
+    rng = np.random.RandomState(5)
+    P = co.param_count(24, 4, False)
+    assert P == 932
+    theta = (rng.randn(6, P) * 0.5).astype(np.float32)
+    init = rng.rand(6, 2, 4).astype(np.float32)
+    fit, ep, steps = co.rollout_walker(theta, init, 2, 120)
+    assert fit.shape == (6,) and ep.shape == (6, 2) and steps.max() <= 120 and steps.min() >= 1
+    fit2, _, _ = co.rollout_walker(theta, init, 2, 120)
+    assert np.array_equal(fit, fit2)
