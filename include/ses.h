@@ -85,6 +85,11 @@ typedef struct ses_config {
 int ses_create(const ses_config *cfg, void *stream, ses_handle **out);
 int ses_destroy(ses_handle *h);
 int ses_sync(ses_handle *h);
+/* Development / test hook: which of the (result-identical) rollout kernels a handle picks.  Every kernel evaluates the
+ * same canonical arithmetic, so no setting changes a result; the defaults are the measured crossovers.  Knobs:
+ * "gru_ep_parallel_max" (default 4096), "gru_mfma_min_e" (12), "gru_sequential" (0), "rollout_mix" (1),
+ * "rollout_waves8" (1024), "rollout_block" (64 | 256).  The library itself reads no environment variable. */
+int ses_set_tuning(ses_handle *h, const char *name, int32_t value);
 const char *ses_last_error(void);
 const char *ses_version(void);
 /* number of parameters P of GymEnvModel(S, A, _, gru)  (networks/neural_network.py:9-18) */

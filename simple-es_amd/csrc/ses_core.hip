@@ -112,8 +112,40 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     h->obs_mask = 0u;
     if (cfg->pomdp && cfg->env_id == SES_ENV_CARTPOLE) h->obs_mask = 0xAu;      // obs[1], obs[3]  (gym_wrapper.py:73-77)
     if (cfg->pomdp && cfg->env_id == SES_ENV_LUNARLANDER) h->obs_mask = 0x2Cu;  // obs[2,3,5]      (gym_wrapper.py:61-66)
+    h->tune_rollout_block = 64;
+    h->tune_gru_mfma_min_e = 12;
+    h->tune_gru_ep_parallel_max = 4096;
+    h->tune_gru_sequential = 0;
+    h->tune_rollout_mix = 1;
+    h->tune_rollout_waves8 = 1024;
     *out = h;
     return SES_OK;
+}
+
+int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
+{
+    SES_REQUIRE(h && name, "ses_set_tuning: null argument");
+    struct Knob {
+        const char *name;
+        int ses_handle::*field;
+        int lo, hi;
+    };
+    static const Knob knobs[] = {{"rollout_block", &ses_handle::tune_rollout_block, 64, 256},
+                                 {"gru_mfma_min_e", &ses_handle::tune_gru_mfma_min_e, 1, 1 << 30},
+                                 {"gru_ep_parallel_max", &ses_handle::tune_gru_ep_parallel_max, 0, 1 << 30},
+                                 {"gru_sequential", &ses_handle::tune_gru_sequential, 0, 1},
+                                 {"rollout_mix", &ses_handle::tune_rollout_mix, 0, 1},
+                                 {"rollout_waves8", &ses_handle::tune_rollout_waves8, 1, 1 << 20}};
+    for (const Knob &k : knobs) {
+        if (std::strcmp(k.name, name) == 0) {
+            SES_REQUIRE(value >= k.lo && value <= k.hi, "ses_set_tuning: %s = %d outside [%d, %d]", name, value, k.lo, k.hi);
+            SES_REQUIRE(k.field != &ses_handle::tune_rollout_block || value == 64 || value == 256,
+                        "ses_set_tuning: rollout_block must be 64 or 256");
+            h->*(k.field) = value;
+            return SES_OK;
+        }
+    }
+    return ses::set_error(SES_ERR_INVALID_ARG, "ses_set_tuning: unknown knob '%s'", name);
 }
 
 int ses_destroy(ses_handle *h)

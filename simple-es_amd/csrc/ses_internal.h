@@ -21,6 +21,13 @@ struct ses_handle {
     // multi-GPU (ses_comm.hip): RCCL communicator of this rank, null until ses_comm_init
     void *comm;
     int comm_rank, comm_world;
+    // kernel-selection thresholds (ses_set_tuning; the defaults are the measured crossovers, ses_rollout.hip)
+    int tune_rollout_block;        // workgroup size of the pure-LPE CartPole MLP rollout: 64 or 256
+    int tune_gru_mfma_min_e;       // eval_ep_num from which GRU rollouts run on the MFMA kernel
+    int tune_gru_ep_parallel_max;  // (offspring x episode) count up to which GRU rollouts use one wave per episode
+    int tune_gru_sequential;       // 1: episode-after-episode GRU kernels only
+    int tune_rollout_mix;          // 0: no mixed LPE-8 / LPE-4 split for mid-sized CartPole MLP populations
+    int tune_rollout_waves8;       // LPE-8 waves of the mixed split
 };
 
 namespace ses {

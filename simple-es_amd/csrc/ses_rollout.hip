@@ -3,8 +3,6 @@
 //   k_fitness_mean         : total_reward / eval_ep_num (loop.py:124)
 //   k_env_step_cartpole    : standalone SoA env.step (gym_wrapper.py:32-45), the HBM-roofline kernel
 //   k_policy_forward_mlp   : standalone population-batched GymEnvModel.forward (neural_network.py:20-36)
-#include <cstdlib>
-
 #include "ses_cartpole.h"
 #include "ses_gru.h"
 #include "ses_gru_lockstep.h"
@@ -890,62 +888,35 @@ template <int LPE>
 static void launch_rollout(const ses_handle *h, const float *theta, const float *init, int per, int n_rows, int mode,
                            double *ep_return, int32_t *ep_steps)
 {
-    static const int block = [] {  // development knob
-        const char *e = getenv("SES_ROLLOUT_BLOCK");
-        return e ? atoi(e) : 64;
-    }();
-    if (block == 256) launch_rollout_b<LPE, 256>(h, theta, init, per, n_rows, mode, ep_return, ep_steps);
+    if (h->tune_rollout_block == 256) launch_rollout_b<LPE, 256>(h, theta, init, per, n_rows, mode, ep_return, ep_steps);
     else launch_rollout_b<LPE, 64>(h, theta, init, per, n_rows, mode, ep_return, ep_steps);
 }
 
-// eval_ep_num from which the GRU rollouts run on the matrix cores (development knob SES_GRU_MFMA_MIN_E).  Measured,
-// POMDP CartPole, 4096 offspring x 500 steps: the MFMA form takes 5.1 ms for any E <= 16 (the padded tile costs the
-// same), the VALU lockstep form 2.4 / 3.5 / 5.6 / 7.2 ms at E = 5 / 8 / 12 / 16 -- the crossover is at 12.
-static int gru_mfma_min_e()
-{
-    static const int v = [] {
-        const char *e = getenv("SES_GRU_MFMA_MIN_E");
-        return e ? atoi(e) : 12;
-    }();
-    return v;
-}
+// eval_ep_num from which the GRU rollouts run on the matrix cores (ses_set_tuning "gru_mfma_min_e", default 12).
+// Measured, POMDP CartPole, 4096 offspring x 500 steps: the MFMA form takes 5.1 ms for any E <= 16 (the padded tile
+// costs the same), the VALU lockstep form 2.4 / 3.5 / 5.6 / 7.2 ms at E = 5 / 8 / 12 / 16 -- the crossover is at 12.
+static int gru_mfma_min_e(const ses_handle *h) { return h->tune_gru_mfma_min_e; }
 
 // Small populations: the chip is far from full and what a rollout costs is the latency of max_step sequential env
 // steps.  The lockstep kernel spends ~1.7 us per step (all E episodes of an offspring in one wave), the
 // episode-after-episode kernel ~0.75 us per step and episode -- launched with one wave per (offspring, episode) it
 // finishes in one episode's time.  Measured, POMDP CartPole, E = 5, 500 steps (lockstep / episode-parallel, ms):
 // 96 offspring 0.87 / 0.37, 400: 0.87 / 0.46, 800: 0.87 / 0.82, 1200: 1.22 / 1.13, 1600: 1.23 / 1.48, 4096: 2.41 / 3.50.
+// (ses_set_tuning "gru_ep_parallel_max": (offspring x episode) waves up to which the form is used, default 4096)
 static bool gru_episode_parallel(const ses_handle *h, long long episodes)
 {
-    static const int limit = [] {  // development knob: (offspring x episode) waves up to which the form is used
-        const char *e = getenv("SES_GRU_EP_PARALLEL_MAX");
-        return e ? atoi(e) : 4096;
-    }();
-    return episodes <= limit && h->cfg.eval_ep_num > 1;
+    return episodes <= h->tune_gru_ep_parallel_max && h->cfg.eval_ep_num > 1;
 }
 
-static bool gru_sequential()
-{
-    static const bool v = [] {  // development knob: SES_GRU_SEQUENTIAL=1 selects the episode-after-episode GRU kernels
-        const char *e = getenv("SES_GRU_SEQUENTIAL");
-        return e && atoi(e) != 0;
-    }();
-    return v;
-}
+// ses_set_tuning "gru_sequential" = 1 selects the episode-after-episode GRU kernels
+static bool gru_sequential(const ses_handle *h) { return h->tune_gru_sequential != 0; }
 
 static void launch_cartpole_mlp(const ses_handle *h, const float *theta, const float *init, int per, int n_rows,
                                 int mode, double *epr, int32_t *ep_steps)
 {
-    static const int allow_mix = [] {  // development knob: SES_ROLLOUT_MIX=0 disables the mixed split
-        const char *e = getenv("SES_ROLLOUT_MIX");
-        return e ? atoi(e) : 1;
-    }();
     const long long episodes = (long long)n_rows * h->cfg.eval_ep_num;
-    if (h->cfg.lanes_per_env == 0 && allow_mix && episodes > 8192 && episodes <= 49152) {
-        static const int waves8_knob = [] {
-            const char *e = getenv("SES_ROLLOUT_WAVES8");
-            return e ? atoi(e) : 1024;                                  // one light wave per SIMD (256 CUs x 4)
-        }();
+    if (h->cfg.lanes_per_env == 0 && h->tune_rollout_mix && episodes > 8192 && episodes <= 49152) {
+        const int waves8_knob = h->tune_rollout_waves8;                // default 1024: one light wave per SIMD (256 CUs x 4)
         const int waves8 = (long long)waves8_knob * 8 < episodes ? waves8_knob : (int)(episodes / 8);
         const int waves4 = ceil_div(episodes - 8ll * waves8, 16);
         if (mode == SES_MODE_FIXED_LENGTH)
@@ -991,16 +962,16 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
     }
     if (h->cfg.env_id == SES_ENV_LUNARLANDER) {
         SES_REQUIRE(mode == SES_MODE_EPISODIC, "ses_rollout: LunarLander has no fixed-length mode");
-        const bool epp = h->cfg.gru && !gru_sequential() && gru_episode_parallel(h, (long long)episodes);
+        const bool epp = h->cfg.gru && !gru_sequential(h) && gru_episode_parallel(h, (long long)episodes);
         if (epp)
             hipLaunchKernelGGL(k_rollout_lander_gru, dim3(ceil_div((long long)episodes, 4)), dim3(256), 0, h->stream,
                                theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step,
                                h->obs_mask, epr, ep_steps, 1);
-        else if (h->cfg.gru && !gru_sequential() && h->cfg.eval_ep_num >= gru_mfma_min_e())
+        else if (h->cfg.gru && !gru_sequential(h) && h->cfg.eval_ep_num >= gru_mfma_min_e(h))
             hipLaunchKernelGGL((k_rollout_gru_mfma<LanderLs, false>), dim3(ceil_div(n_rows, 4)), dim3(256), 0,
                                h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
                                h->cfg.max_step, h->obs_mask, epr, ep_steps);
-        else if (h->cfg.gru && !gru_sequential())
+        else if (h->cfg.gru && !gru_sequential(h))
             hipLaunchKernelGGL((k_rollout_gru_lockstep<LanderLs, false, 1>), dim3(n_rows), dim3(64), 0,
                                h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
                                h->cfg.max_step, h->obs_mask, epr, ep_steps);
@@ -1056,7 +1027,7 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
                 hipLaunchKernelGGL((k_rollout_cartpole_mlp<4, false, 64, true>), dim3(blocks), dim3(64), 0, h->stream, theta,
                                    init, init_per_offspring, n_rows, E, h->P, T, h->obs_mask, epr, ep_steps);
         }
-    } else if (h->cfg.gru && !gru_sequential() && gru_episode_parallel(h, (long long)episodes)) {
+    } else if (h->cfg.gru && !gru_sequential(h) && gru_episode_parallel(h, (long long)episodes)) {
         const int blocks = ceil_div((long long)episodes, 4);
         if (mode == SES_MODE_FIXED_LENGTH)
             hipLaunchKernelGGL((k_rollout_cartpole_gru<true>), dim3(blocks), dim3(256), 0, h->stream, theta, init,
@@ -1066,7 +1037,7 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
             hipLaunchKernelGGL((k_rollout_cartpole_gru<false>), dim3(blocks), dim3(256), 0, h->stream, theta, init,
                                init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
                                epr, ep_steps, 1);
-    } else if (h->cfg.gru && !gru_sequential() && h->cfg.eval_ep_num >= gru_mfma_min_e()) {
+    } else if (h->cfg.gru && !gru_sequential(h) && h->cfg.eval_ep_num >= gru_mfma_min_e(h)) {
         const int blocks = ceil_div(n_rows, 4);
         if (mode == SES_MODE_FIXED_LENGTH)
             hipLaunchKernelGGL((k_rollout_gru_mfma<CartPoleLs, true>), dim3(blocks), dim3(256), 0, h->stream, theta,
@@ -1076,7 +1047,7 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
             hipLaunchKernelGGL((k_rollout_gru_mfma<CartPoleLs, false>), dim3(blocks), dim3(256), 0, h->stream, theta,
                                init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
                                epr, ep_steps);
-    } else if (h->cfg.gru && !gru_sequential()) {
+    } else if (h->cfg.gru && !gru_sequential(h)) {
         const int blocks = ceil_div(n_rows, 4);
         if (mode == SES_MODE_FIXED_LENGTH)
             hipLaunchKernelGGL((k_rollout_gru_lockstep<CartPoleLs, true, 4>), dim3(blocks), dim3(256), 0, h->stream, theta,

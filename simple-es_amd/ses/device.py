@@ -6,6 +6,7 @@ All checks happen on the host BEFORE a kernel is launched: a wrong shape raises 
 reaches the GPU.
 """
 import ctypes
+import os
 
 import torch
 
@@ -63,6 +64,15 @@ class HipES:
             self.stream = torch.cuda.current_stream(self.device)
             check(lib.ses_create(ctypes.byref(cfg), ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(self._h)),
                   "ses_create")
+        # test hook: SES_TUNING="gru_ep_parallel_max=0,gru_mfma_min_e=1" forces a kernel path for every handle of the
+        # process (the library reads no environment itself; tests/test_gpu_gru.py reruns the parity suites this way)
+        for item in filter(None, os.environ.get("SES_TUNING", "").split(",")):
+            name, _, value = item.partition("=")
+            self.set_tuning(name.strip(), int(value))
+
+    def set_tuning(self, name, value):
+        """ses_set_tuning: choose among the result-identical rollout kernels (include/ses.h lists the knobs)."""
+        check(self._lib.ses_set_tuning(self._h, name.encode(), int(value)), "ses_set_tuning")
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -137,9 +137,9 @@ def test_lander_gru_rollout_on_the_matrix_cores_bit_exact():
     es.close()
 
 
-@pytest.mark.parametrize("knobs", [{"SES_GRU_EP_PARALLEL_MAX": "0"},
-                                   {"SES_GRU_EP_PARALLEL_MAX": "0", "SES_GRU_MFMA_MIN_E": "1"},
-                                   {"SES_GRU_EP_PARALLEL_MAX": "1000000"}],
+@pytest.mark.parametrize("knobs", [{"SES_TUNING": "gru_ep_parallel_max=0"},
+                                   {"SES_TUNING": "gru_ep_parallel_max=0,gru_mfma_min_e=1"},
+                                   {"SES_TUNING": "gru_ep_parallel_max=1000000"}],
                          ids=["lockstep", "mfma", "episode_parallel"])
 def test_gru_parity_suites_on_every_kernel_path(knobs):
     """ses_rollout picks the GRU kernel from the population size and episode count: one wave per (offspring, episode)

@@ -33,7 +33,7 @@ def main():
     rng = np.random.RandomState(args.seed)
     tally = {}
     for case in range(args.cases):
-        kind = rng.choice(["mlp", "mlp", "gru", "gru_mfma", "lander", "lander_mlp", "spread"])
+        kind = rng.choice(["mlp", "mlp", "gru", "gru_mfma", "lander", "lander_mlp", "walker", "spread"])
         mode = int(rng.randint(0, 2))
         shared = bool(rng.randint(0, 2))
         sigma = float(rng.choice([0.05, 0.3, 1.0, 3.0]))
@@ -68,6 +68,15 @@ def main():
             theta = (rng.randn(n, es.P) * min(sigma, 1.0)).astype(np.float32)
             init = rng.uniform(0, 1, (E, 16) if shared else (n, E, 16)).astype(np.float32)
             ref = co.rollout_lander(theta, init, E, T, gru=gru, obs_mask=0b101100 if pomdp else 0)
+            fit, ret, steps = es.rollout(dev(theta), dev(init), want_episodes=True)
+            ok = (np.array_equal(steps.cpu().numpy(), ref[2]) and np.array_equal(bits(ret.cpu().numpy()), bits(ref[1])) and
+                  np.array_equal(bits(fit.cpu().numpy()), bits(ref[0])))
+        elif kind == "walker":
+            n, E, T = int(rng.choice([1, 5, 33])), int(rng.choice([1, 2, 5])), int(rng.choice([5, 60, 150]))
+            es = HipES("BipedalWalker-v3", 24, 4, False, False, max_step=T, eval_ep_num=E)
+            theta = (rng.randn(n, es.P) * sigma).astype(np.float32)
+            init = rng.uniform(0, 1, (E, 4) if shared else (n, E, 4)).astype(np.float32)
+            ref = co.rollout_walker(theta, init, E, T)
             fit, ret, steps = es.rollout(dev(theta), dev(init), want_episodes=True)
             ok = (np.array_equal(steps.cpu().numpy(), ref[2]) and np.array_equal(bits(ret.cpu().numpy()), bits(ref[1])) and
                   np.array_equal(bits(fit.cpu().numpy()), bits(ref[0])))
