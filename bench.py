@@ -269,6 +269,11 @@ def summarise(job, steps, times):
 
 
 def run_rank(args):
+    # stdout carries ONE line, the JSON: everything else this process or its libraries print (RCCL's version banner,
+    # warnings) goes to stderr -- fd 1 is pointed at fd 2 for the whole run, the line is written to the saved fd.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -282,7 +287,7 @@ def run_rank(args):
         dist.all_gather_object(got, rank)
         dist.barrier()
         if rank == 0:
-            print(json.dumps({"rendezvous": "ok", "world": world, "ranks": got}))
+            os.write(real_stdout, (json.dumps({"rendezvous": "ok", "world": world, "ranks": got}) + "\n").encode())
         dist.destroy_process_group()
         return 0
     n_dev = torch.cuda.device_count()
@@ -404,22 +409,57 @@ def run_rank(args):
                                              "mfma_peak_tflops": 157.3,
                                              "mfma_frac": flops / (roll_ms * 1e-3) / 157.3e12,
                                              "mfma": "v_mfma_f32_16x16x4_f32; MfmaUtil 56 % in profiles/r01_sq_gru_mfma.txt"})
+        # VALU issue roofline of the rollout kernel: instruction count from the newest committed SQ counter profile of
+        # this same workload (attached only while the kernel's machine code is the profiled one), duration live
+        suffix, frag = ("_sq_gru_lockstep.json", "k_rollout_gru_lockstep") if args.gru else ("_sq_rollout.json", "k_rollout_cartpole_mlp")
         sq = None
         for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
-            if name.endswith("_sq_rollout.json"):
+            if name.endswith(suffix):
                 sq = os.path.join(ROOT, "profiles", name)
-        if sq and not args.gru and n_local == 4096 and E == 5 and T == 500:
-            # VALU issue roofline of the fused kernel: instruction count from the committed SQ counter profile of
-            # this same workload (attached only while the kernel's machine code is the profiled one), duration live
+        if sq and n_local == 4096 and E == 5 and T == 500:
             prof = json.load(open(sq))
-            now = kernel_code_hash("k_rollout_cartpole_mlp")
+            now = kernel_code_hash(frag)
             result["rollout_kernel"]["kernel_code_sha256"] = now
             if not prof.get("kernel_code_sha256") or prof["kernel_code_sha256"] == now:
                 rate = prof["per_dispatch"]["SQ_INSTS_VALU"] / (roll_ms * 1e-3)
-                result["rollout_kernel"].update({"valu_wave_instr_per_s": rate,
+                result["rollout_kernel"].update({"valu_wave_instr_per_dispatch": prof["per_dispatch"]["SQ_INSTS_VALU"],
+                                                 "valu_wave_instr_per_s": rate,
                                                  "valu_issue_peak_per_s": prof["peak_valu_wave_instr_per_s"],
                                                  "valu_issue_frac": rate / prof["peak_valu_wave_instr_per_s"],
                                                  "valu_source": os.path.relpath(sq, ROOT)})
+            else:
+                result["rollout_kernel"]["valu_note"] = (f"{os.path.relpath(sq, ROOT)} was collected on different machine "
+                                                         "code of this kernel: not attached")
+        # BASELINE.json configs[2]: LunarLanderContinuous-v2 POMDP, GRU policy, 4096 offspring (conf/lunarlander_openai.yaml):
+        # one rollout of first-generation policies (sigma = init_sigma around the zero network), episodic
+        if not args.no_extras and not args.gru:
+            try:
+                from ses import HipES
+                c3 = HipES("LunarLanderContinuous-v2", 8, 4, False, True, pomdp=True, max_step=300, eval_ep_num=5)
+                th = c3.perturb(c3.zeros(c3.P), 0.168, 0, 0, 0, 4096)
+                ini = c3.init_states_uniform(0, 0, 0, 4096)
+                fit3 = c3.empty(4096)
+                c3.rollout(th, ini, fitness=fit3)
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(3):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    c3.rollout(th, ini, fitness=fit3)
+                    e1.record()
+                    e1.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                _, _, st3 = c3.rollout(th, ini, want_episodes=True)
+                n3 = int(st3.sum().item())
+                ms3 = statistics.median(ts)
+                result["c3_lunarlander_pomdp_gru_4096"] = {
+                    "rollout_ms": ms3, "env_steps": n3, "env_steps_per_s": n3 / (ms3 * 1e-3), "mean_episode_steps": n3 / (4096 * 5),
+                    "env": "gym's lunar_lander.py restated on a Box2D-style world: 3 bodies, 2 revolute joints, 180 velocity + "
+                           "<= 60 position iterations per step (parity with gym / Box2D unpinned; GPU == CPU build bit for bit)",
+                    "bound": "valu issue + the latency of the sequential solver (profiles: *_sq_c3_lander.json)"}
+                c3.close()
+            except Exception as exc:
+                result["c3_error"] = repr(exc)
         if not args.no_roofline:
             try:
                 result["roofline"] = env_step_roofline(es, args.roofline_envs)
@@ -457,7 +497,8 @@ def run_rank(args):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
     return 0
 
 

@@ -42,6 +42,7 @@ SES_DEV float register_constant(float c)
 // angle, denominator) with the policy's LDS table reads; the arithmetic and its order are unchanged.
 struct CartPolePre {
     float sn, cs, q, gsn, den;
+    float rden;   // device: refined reciprocal of den for the quotient in cartpole_post (see there); host: unused
 };
 
 SES_DEV CartPolePre cartpole_pre_from(const CartPoleState &s, float sn, float cs)
@@ -52,6 +53,14 @@ SES_DEV CartPolePre cartpole_pre_from(const CartPoleState &s, float sn, float cs
     p.q = CP_PML_OVER_MASS * (s.thd * s.thd);
     p.gsn = CP_GRAVITY * p.sn;
     p.den = fma_(CP_DEN_C1, p.cs * p.cs, CP_DEN_C0);
+#if defined(__HIPCC__)
+    {   // first half of the IEEE division num / den of cartpole_post, the part that does not depend on the action
+        const float r0 = __builtin_amdgcn_rcpf(p.den);
+        p.rden = fma_(fma_(-p.den, r0, 1.0f), r0, r0);
+    }
+#else
+    p.rden = 0.0f;
+#endif
     return p;
 }
 
@@ -82,17 +91,46 @@ SES_DEV CartPolePre cartpole_pre(const CartPoleState &s)
 // advances s in place; returns true when the NEW state is terminal
 // th_clamp: CP_TH_CLAMP; a fused loop passes it from a register it set up once (register_constant) so that the
 // clamp is a single v_med3_f32 -- with the literal the compiler emits v_max + v_min, one literal each
-SES_DEV bool cartpole_post(CartPoleState &s, const CartPolePre &p, int action, float th_clamp = CP_TH_CLAMP)
+// num / den, correctly rounded.  den = l * (4/3 - mp cos^2 / M) lies in [0.62, 0.67] and |num| < 1e8, so the operand
+// scaling and the special-case fix-up of the generic expansion (v_div_scale x2, v_div_fixup) never act: what remains is
+// its Newton-Raphson core -- one step on the reciprocal (done in cartpole_pre_from, off the action's critical path), two
+// on the quotient, final fma -- which yields the IEEE quotient bit for bit (the oracle divides with `/`;
+// tools/fuzz_parity.py and the parity suites compare every return).
+SES_DEV float cartpole_quotient(float num, const CartPolePre &p)
+{
+#if defined(__HIPCC__)
+    const float r = p.rden;
+    float q = num * r;
+    q = fma_(fma_(-p.den, q, num), r, q);
+    return fma_(fma_(-p.den, q, num), r, q);
+#else
+    return num / p.den;
+#endif
+}
+
+// lim_clamp: CP_CLAMP from a register (register_constant), like th_clamp: one v_med3_f32 per clamp instead of two
+// instructions with a literal each
+SES_DEV float clamp_sym_reg(float v, float lim)
+{
+#if defined(__HIPCC__)
+    return __builtin_amdgcn_fmed3f(v, -lim, lim);
+#else
+    return clamp_sym(v, lim);
+#endif
+}
+
+SES_DEV bool cartpole_post(CartPoleState &s, const CartPolePre &p, int action, float th_clamp = CP_TH_CLAMP,
+                           float lim_clamp = CP_CLAMP)
 {
     const float fom = action == 1 ? CP_FORCE_OVER_MASS : -CP_FORCE_OVER_MASS;
     // temp = (F + pml*thd^2*sin)/M ; thetaacc = (g*sin - cos*temp) / (l*(4/3 - mp*cos^2/M)) ;
     // xacc = temp - pml*thetaacc*cos/M   -- constant divisions folded into multipliers, one true division
     const float temp = fma_(p.q, p.sn, fom);
     const float num = fma_(-p.cs, temp, p.gsn);
-    const float thacc = num / p.den;
+    const float thacc = cartpole_quotient(num, p);
     const float xacc = fma_(-CP_PML_OVER_MASS * thacc, p.cs, temp);
-    const float nx = clamp_sym(fma_(CP_TAU, s.xd, s.x), CP_CLAMP);
-    const float nxd = clamp_sym(fma_(CP_TAU, xacc, s.xd), CP_CLAMP);
+    const float nx = clamp_sym_reg(fma_(CP_TAU, s.xd, s.x), lim_clamp);
+    const float nxd = clamp_sym_reg(fma_(CP_TAU, xacc, s.xd), lim_clamp);
 #if defined(__HIPCC__)
     // v_med3_f32(v, -lim, lim) == min(max(v, -lim), lim) for lim >= 0, NaN included (it returns the minimum of the
     // non-NaN operands, as fmin / fmax do); the compiler makes this rewrite itself when lim is a literal
@@ -100,7 +138,7 @@ SES_DEV bool cartpole_post(CartPoleState &s, const CartPolePre &p, int action, f
 #else
     const float nth = clamp_sym(fma_(CP_TAU, s.thd, s.th), th_clamp);
 #endif
-    const float nthd = clamp_sym(fma_(CP_TAU, thacc, s.thd), CP_CLAMP);
+    const float nthd = clamp_sym_reg(fma_(CP_TAU, thacc, s.thd), lim_clamp);
     s.x = nx; s.xd = nxd; s.th = nth; s.thd = nthd;
     return (nx < -CP_X_LIMIT) || (nx > CP_X_LIMIT) || (nth < -CP_THETA_LIMIT) || (nth > CP_THETA_LIMIT);
 }

@@ -31,11 +31,12 @@ template <>
 struct CartPoleSim<false> {
     CartPoleState st;
     CartPolePre pre;
-    float th_clamp;
+    float th_clamp, lim_clamp;
     __device__ __forceinline__ void init(const float *s0)
     {
         st = CartPoleState{s0[0], s0[1], s0[2], s0[3]};
         th_clamp = register_constant(CP_TH_CLAMP);
+        lim_clamp = register_constant(CP_CLAMP);
     }
     __device__ __forceinline__ void observe(float (&o)[4]) const { o[0] = st.x; o[1] = st.xd; o[2] = st.th; o[3] = st.thd; }
     // |pole angle| <= SINCOS_SMALL_MAX for this lane now -- and then for the whole episode (CP_TH_CLAMP)
@@ -55,7 +56,7 @@ struct CartPoleSim<false> {
     __device__ __forceinline__ bool advance(int action, bool keep_old)
     {
         CartPoleState ns = st;
-        const bool term = cartpole_post(ns, pre, action, th_clamp);
+        const bool term = cartpole_post(ns, pre, action, th_clamp, lim_clamp);
         st.x = keep_old ? st.x : ns.x;
         st.xd = keep_old ? st.xd : ns.xd;
         st.th = keep_old ? st.th : ns.th;

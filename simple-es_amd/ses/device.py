@@ -5,8 +5,10 @@ hand-written gfx950 kernel inside libses_hip.so, enqueued on torch's current HIP
 All checks happen on the host BEFORE a kernel is launched: a wrong shape raises here, it never
 reaches the GPU.
 """
+import contextlib
 import ctypes
 import os
+import sys
 
 import torch
 
@@ -24,6 +26,21 @@ def param_count(num_state, num_action, gru):
 
 def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """fd-level redirect of stdout to stderr around a native call that prints (RCCL's banner): programs that emit
+    machine-readable lines on stdout (bench.py, run_es.py --log pipelines) stay clean."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 class HipES:
@@ -139,14 +156,16 @@ class HipES:
     def comm_unique_id():
         """128 opaque bytes from ncclGetUniqueId; rank 0 creates them, every rank passes them to comm_init."""
         buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
-        check(_lib.load().ses_comm_unique_id(buf), "ses_comm_unique_id")
+        with _stdout_to_stderr():
+            check(_lib.load().ses_comm_unique_id(buf), "ses_comm_unique_id")
         return buf.raw
 
     def comm_init(self, rank, world, unique_id):
         if len(unique_id) != _lib.COMM_ID_BYTES:
             raise SesError(f"comm_init: unique id must be {_lib.COMM_ID_BYTES} bytes")
         buf = ctypes.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
-        check(self._lib.ses_comm_init(self._h, int(rank), int(world), buf), "ses_comm_init")
+        with _stdout_to_stderr():          # RCCL prints a version banner on stdout when it initialises
+            check(self._lib.ses_comm_init(self._h, int(rank), int(world), buf), "ses_comm_init")
 
     def comm_info(self):
         """(rank, world, rccl_version_code); world == 0 means the handle has no communicator."""
