@@ -60,6 +60,9 @@ B2_FN float b2min(float a, float b) { return a < b ? a : b; }
 B2_FN float b2max(float a, float b) { return a > b ? a : b; }
 B2_FN float b2clamp(float a, float lo, float hi) { return b2max(lo, b2min(a, hi)); }
 B2_FN float b2abs(float a) { return a > 0.0f ? a : -a; }
+// clamp to [-lim, lim] in the solver's inner loops: fmin / fmax (one instruction each on the device; same value as
+// b2clamp for every non-NaN input)
+B2_FN float b2clamp_sym(float a, float lim) { return __builtin_fmaxf(-lim, __builtin_fminf(a, lim)); }
 
 struct JointDef {
     int a, b;                        // body indices
@@ -467,7 +470,7 @@ B2_FN void joint_solve_velocity(World<D> &w, int j, const JointTmp &t)
     if (!equal_limits) {                                      // motor (enableMotor = true)
         const float Cdot = (B.w - A.w) - J.motor_speed;
         const float old = J.im;
-        J.im = b2clamp(__builtin_fmaf(-t.motor_mass, Cdot, old), -t.max_impulse, t.max_impulse);
+        J.im = b2clamp_sym(__builtin_fmaf(-t.motor_mass, Cdot, old), t.max_impulse);
         const float impulse = J.im - old;
         A.w = __builtin_fmaf(-iA, impulse, A.w);
         B.w = __builtin_fmaf(iB, impulse, B.w);
@@ -483,6 +486,7 @@ B2_FN void joint_solve_velocity(World<D> &w, int j, const JointTmp &t)
         const float new_impulse = J.iz + iz;                  // (inactive limit: J.iz = iz = 0, never released)
         const bool release = J.state == LIMIT_LOWER ? new_impulse < 0.0f : new_impulse > 0.0f;
         if (release) {                                         // the limit lets go: solve the point rows alone
+            B2_RARE_PATH;                                      // (rare: keep it a branch, not a select over both results)
             const float rx = __builtin_fmaf(J.iz, t.ezx, -c1x), ry = __builtin_fmaf(J.iz, t.ezy, -c1y);
             ix = __builtin_fmaf(t.j00, rx, t.j01 * ry);
             iy = __builtin_fmaf(t.j01, rx, t.j11 * ry);
@@ -634,7 +638,7 @@ B2_FN void contact_solve_velocity(Manifold &m, const ContactTmp &t, Body &B, con
             const float dvx = __builtin_fmaf(-B.w, t.rby[i], B.vx), dvy = __builtin_fmaf(B.w, t.rbx[i], B.vy);
             const float vt = __builtin_fmaf(dvx, tx, dvy * ty);
             const float max_friction = friction * m.ni[i];
-            const float new_impulse = b2clamp(__builtin_fmaf(-t.tmass[i], vt, m.ti[i]), -max_friction, max_friction);
+            const float new_impulse = b2clamp_sym(__builtin_fmaf(-t.tmass[i], vt, m.ti[i]), max_friction);
             const float lambda = new_impulse - m.ti[i];
             m.ti[i] = new_impulse;
             const float Px = lambda * tx, Py = lambda * ty;

@@ -17,6 +17,7 @@ void o_philox_raw(const uint32_t *ctr, const uint32_t *key, uint32_t *out);
 #define B2_SINCOS(a, s, c) o_sincosf((a), &(s), &(c))
 #define B2_SQRT(x) sqrtf(x)
 #define B2_FLOOR(x) floorf(x)
+#define B2_RARE_PATH asm volatile("")
 #define B2_F2U(f) o_f2u(f)
 
 // two uniforms in (-1, 1) from the episode key and the step counter: the same Philox call as the device

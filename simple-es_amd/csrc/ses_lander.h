@@ -20,6 +20,7 @@
 #define B2_SINCOS(a, s, c) ses::sincos_((a), (s), (c))
 #define B2_SQRT(x) __builtin_sqrtf(x)
 #define B2_FLOOR(x) __builtin_floorf(x)
+#define B2_RARE_PATH asm volatile("")
 #define B2_F2U(f) ses::f2u(f)
 // two uniforms in (-1, 1) from the episode key and the step counter (oracle: ses_b2_oracle.cpp b2o_dispersion)
 #define B2_DISPERSION(k0, k1, step, d0, d1)                                                                     \
