@@ -168,6 +168,18 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
 int ses_rank_center(ses_handle *h, const float *fitness, int32_t n, int32_t *rank, double *weights, float *best);
 
 /* ---- K5: ES gradient + Adam (offspring_strategies.py:400-416, optimizers.py:13-24,42-57) ---- */
+/* One generation's fitness loop of openai_es (offspring_strategies.py:380-419 followed by _gen_offsprings :284-328) in
+ * four launches: rank keys, rank count (sort + search above 8192), ES-gradient partials with the rank-centring weights
+ * formed inline, Adam + Philox perturbation of the next population.  Bit-identical to ses_rank_center +
+ * ses_es_update_philox(skip_row0 = 1) + ses_perturb called one after the other (tests/test_gpu_host_mirror.py).
+ *   fitness[n]: the gathered fitness of the evaluated population (noise generation `gen`, std `sigma`);
+ *   (mu, m, v)_in -> (mu, m, v)_out: distinct float32[P] buffers, the caller ping-pongs them;
+ *   theta_next[n_rows, P]: rows [first_row, first_row + n_rows) of the next population (noise generation next_gen, std
+ *   next_sigma; global row 0 = the new mu itself); best: optional float32[1] <- max(fitness). */
+int ses_openai_generation(ses_handle *h, const float *fitness, int32_t n, uint64_t seed, uint64_t gen, double lr,
+                          double sigma, double adam_a, const float *mu_in, const float *m_in, const float *v_in,
+                          float *mu_out, float *m_out, float *v_out, float next_sigma, uint64_t next_gen,
+                          int64_t first_row, int32_t n_rows, float *theta_next, float *best);
 /*
  * grad = (-lr / (n*sigma)) * sum_i weights[i] * eps_i ;  Adam (beta1 = 0.99, beta2 = 0.999, eps = 1e-8)
  * with step scale adam_a = lr*sqrt(1-beta2^t)/(1-beta1^t) computed by the host; mu, m, v updated in place.

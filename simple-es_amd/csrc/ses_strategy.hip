@@ -266,6 +266,89 @@ __global__ __launch_bounds__(256) void k_es_apply(const float *__restrict__ part
     mu[p] = muv; m[p] = mv; v[p] = vv;
 }
 
+// ---- the openai_es fitness loop in four launches (ses_openai_generation) -----------------------------------------
+// Same arithmetic as k_rank_weights + k_es_grad_partial + k_es_apply + k_perturb, regrouped so that a generation needs
+// four small launches after the rollout instead of seven:
+//   * the rank-centring weight of a row is a closed form of its rank: formed where it is used (stage 1 of the gradient)
+//     instead of being written and re-read; the thread that meets rank 0 also reports best = max(fitness);
+//   * Adam's update of (mu, m, v) -- P parameters -- is recomputed by every thread of the perturbation kernel for the
+//     four parameters it perturbs (chunk partials added in the same ascending order), so the next population is written
+//     by the launch that finishes the update; the threads of the shard's first row store the new (mu, m, v).  Old and
+//     new vectors are distinct buffers (the caller ping-pongs): no thread can read a value another one has updated.
+__global__ __launch_bounds__(256) void k_es_grad_partial_ranked(const int32_t *__restrict__ rank,
+                                                                const float *__restrict__ fitness, int n, int skip_row0,
+                                                                uint64_t seed, uint64_t gen, int P4,
+                                                                float *__restrict__ partial, float *__restrict__ best)
+{
+    __shared__ float red[4][256];
+    const int q = blockIdx.x;
+    const int row0 = blockIdx.y * ES_CHUNK;
+    const int row1 = row0 + ES_CHUNK < n ? row0 + ES_CHUNK : n;
+    const double nm1 = (double)(n - 1);
+    const double sd = sqrt((double)(n + 1) / (12.0 * nm1));           // closed-form std of the rank grid
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = row0 + threadIdx.x; i < row1; i += 256) {
+        const int r = rank[i];
+        if (best && q == 0 && r == 0) *best = fitness[i];              // max(rewards), loop.py:82-84 `best_reward`
+        if (skip_row0 && i == 0) continue;
+        const double centred = ((double)(n - 1 - r) / nm1) - 0.5;      // offspring_strategies.py:394-396
+        const float w = (float)(centred / sd);
+        float z[4];
+        normal4(seed, gen, (uint32_t)i, (uint32_t)q, z);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) acc[l] = fma_(w, z[l], acc[l]);
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) red[l][threadIdx.x] = acc[l];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+#pragma unroll
+            for (int l = 0; l < 4; ++l) red[l][threadIdx.x] = red[l][threadIdx.x] + red[l][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) partial[(size_t)blockIdx.y * P4 + 4 * q + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// one thread = (row of this rank's shard, parameter quad): Adam for the quad, then the row's perturbation of the new mu
+// (global row 0 is the unperturbed mu: openai_es member 0, offspring_strategies.py:300-304)
+__global__ __launch_bounds__(256) void k_es_apply_perturb(const float *__restrict__ partial, int chunks, int P, int P4,
+                                                          float update_factor, double adam_a,
+                                                          const float *__restrict__ mu_in, const float *__restrict__ m_in,
+                                                          const float *__restrict__ v_in, float *__restrict__ mu_out,
+                                                          float *__restrict__ m_out, float *__restrict__ v_out,
+                                                          float sigma, uint64_t seed, uint64_t gen, long long first_row,
+                                                          int n_rows, int quads, float *__restrict__ theta)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)(n_rows > 0 ? n_rows : 1) * quads) return;
+    const int i = (int)(t / quads);
+    const int q = (int)(t - (long long)i * quads);
+    const int lim = P - 4 * q < 4 ? P - 4 * q : 4;
+    float mu_new[4];
+    for (int l = 0; l < lim; ++l) {
+        const int p = 4 * q + l;
+        float sum = partial[p];
+        for (int c = 1; c < chunks; ++c) sum = sum + partial[(size_t)c * P4 + p];
+        const float g = sum * update_factor;                              // offspring_strategies.py:414
+        float muv = mu_in[p], mv = m_in[p], vv = v_in[p];
+        adam_apply(g, adam_a, muv, mv, vv);
+        mu_new[l] = muv;
+        if (i == 0) { mu_out[p] = muv; m_out[p] = mv; v_out[p] = vv; }
+    }
+    if (n_rows <= 0) return;                                              // a rank without rows still keeps (mu, m, v)
+    float *dst = theta + (size_t)i * P + 4 * q;
+    const long long row = first_row + i;
+    if (row == 0) {
+        for (int l = 0; l < lim; ++l) dst[l] = mu_new[l];
+        return;
+    }
+    float z[4];
+    normal4(seed, gen, (uint32_t)row, (uint32_t)q, z);
+    for (int l = 0; l < lim; ++l) dst[l] = fma_(sigma, z[l], mu_new[l]);
+}
+
 // Reference-order accumulation over stored (mu + eps) rows: one thread per parameter, sequential over
 // offspring, float32 accumulator with float64 products (offspring_strategies.py:409-414 under numpy 2).
 __global__ __launch_bounds__(64) void k_es_update_stored(const double *__restrict__ weights, int n,
@@ -457,6 +540,53 @@ int ses_es_update_philox(ses_handle *h, const double *weights, int32_t n, int32_
                        P4, partial);
     hipLaunchKernelGGL(k_es_apply, dim3(ceil_div(h->P, 256)), dim3(256), 0, h->stream, partial, chunks, h->P, P4,
                        (float)uf, adam_a, mu, m, v, grad_out);
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+int ses_openai_generation(ses_handle *h, const float *fitness, int32_t n, uint64_t seed, uint64_t gen, double lr,
+                          double sigma, double adam_a, const float *mu_in, const float *m_in, const float *v_in,
+                          float *mu_out, float *m_out, float *v_out, float next_sigma, uint64_t next_gen,
+                          int64_t first_row, int32_t n_rows, float *theta_next, float *best)
+{
+    SES_REQUIRE(h && fitness && mu_in && m_in && v_in && mu_out && m_out && v_out, "ses_openai_generation: null argument");
+    SES_REQUIRE(mu_in != mu_out && m_in != m_out && v_in != v_out, "ses_openai_generation: in and out vectors must be distinct buffers");
+    SES_REQUIRE(n >= 2 && sigma != 0.0, "ses_openai_generation: bad n / sigma");
+    SES_REQUIRE(n_rows >= 0 && first_row >= 0 && first_row + n_rows <= (int64_t)n && (n_rows == 0 || theta_next),
+                "ses_openai_generation: shard rows [%lld, +%d) outside the population of %d", (long long)first_row, n_rows, n);
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    // scratch: rank keys | sorted tiles or nothing | ranks | gradient partials
+    long long jt = ((long long)n * n / (256ll * 2048ll) + 63) / 64 * 64;
+    if (jt < 64) jt = 64;
+    if (jt > 8192) jt = 8192;
+    const int tiles = ceil_div(n, RANK_TILE);
+    const int quads = (h->P + 3) / 4, P4 = 4 * quads;
+    const int chunks = ceil_div(n, ES_CHUNK);
+    const size_t key_bytes = (sizeof(unsigned long long) * (size_t)n + 255) / 256 * 256;
+    const size_t sorted_bytes = sizeof(unsigned long long) * (size_t)tiles * RANK_TILE;
+    const size_t rank_bytes = (sizeof(int32_t) * (size_t)n + 255) / 256 * 256;
+    const int rc = ensure_reduce_scratch(h, key_bytes + sorted_bytes + rank_bytes + sizeof(float) * (size_t)chunks * P4);
+    if (rc != SES_OK) return rc;
+    unsigned long long *keys = (unsigned long long *)h->red_scratch;
+    unsigned long long *sorted = (unsigned long long *)((char *)h->red_scratch + key_bytes);
+    int32_t *rank = (int32_t *)((char *)h->red_scratch + key_bytes + sorted_bytes);
+    float *partial = (float *)((char *)h->red_scratch + key_bytes + sorted_bytes + rank_bytes);
+    hipLaunchKernelGGL(k_rank_keys, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, fitness, n, keys, rank);
+    if (n > RANK_SORT_MIN) {
+        hipLaunchKernelGGL(k_rank_tile_sort, dim3(tiles), dim3(RANK_TILE / 2), 0, h->stream, keys, n, sorted);
+        hipLaunchKernelGGL(k_rank_search, dim3(ceil_div(n, 256), tiles), dim3(256), 0, h->stream, keys, sorted, n, rank);
+    } else {
+        hipLaunchKernelGGL(k_rank_count, dim3(ceil_div(n, 256), ceil_div(n, jt)), dim3(256), 0, h->stream, keys, n,
+                           (int)jt, rank);
+    }
+    double uf = lr / ((double)n * sigma);            // offspring_strategies.py:406-408
+    uf *= -1.0;
+    hipLaunchKernelGGL(k_es_grad_partial_ranked, dim3(quads, chunks), dim3(256), 0, h->stream, rank, fitness, n, 1, seed,
+                       gen, P4, partial, best);
+    const long long threads = (long long)(n_rows > 0 ? n_rows : 1) * quads;
+    hipLaunchKernelGGL(k_es_apply_perturb, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, partial, chunks, h->P, P4,
+                       (float)uf, adam_a, mu_in, m_in, v_in, mu_out, m_out, v_out, next_sigma, seed, next_gen,
+                       (long long)first_row, n_rows, quads, theta_next);
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;
 }

@@ -73,19 +73,32 @@ class PendingReward:
 
 
 class _ReadbackRing:
-    """`depth` pinned host slots + events, reused round-robin (the loop keeps at most two generations in flight)."""
+    """`depth` (device float, pinned host float, events) slots reused round-robin (the loop keeps at most two
+    generations in flight).  `best` is the device slot the current generation's kernels write; push() copies it to
+    the host on a SIDE stream, behind an event recorded on the launch stream: the next generation's kernels are
+    not queued behind a 5 us device-to-host copy."""
 
     def __init__(self, device, depth=4):
-        self.best = torch.zeros(1, dtype=torch.float32, device=device)      # written by ses_rank_center
-        self.slots = [(torch.zeros(1, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(depth)]
+        self.dev_slots = [torch.zeros(1, dtype=torch.float32, device=device) for _ in range(depth)]
+        self.slots = [(torch.zeros(1, dtype=torch.float32).pin_memory(), torch.cuda.Event(), torch.cuda.Event())
+                      for _ in range(depth)]
+        self.side = torch.cuda.Stream(device=device)
         self.k = 0
 
+    @property
+    def best(self):
+        return self.dev_slots[self.k]
+
     def push(self):
-        host, event = self.slots[self.k]
+        host, produced, copied = self.slots[self.k]
+        src = self.dev_slots[self.k]
         self.k = (self.k + 1) % len(self.slots)
-        host.copy_(self.best, non_blocking=True)
-        event.record()
-        return PendingReward(host, event)
+        produced.record()                               # on the launch stream, after the kernel that wrote `src`
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(produced)
+            host.copy_(src, non_blocking=True)
+            copied.record()
+        return PendingReward(host, copied)
 
 
 class _DeviceStrategy(BaseOffspringStrategy):
@@ -315,11 +328,13 @@ class simple_evolution(_DeviceStrategy):
 
 
 class openai_es(_DeviceStrategy):
-    def __init__(self, init_sigma, sigma_decay, learning_rate, offspring_num, noise="philox", seed=0):
+    def __init__(self, init_sigma, sigma_decay, learning_rate, offspring_num, noise="philox", seed=0, fused=True):
         super().__init__(init_sigma, sigma_decay, offspring_num, noise, seed)
         self.learning_rate = learning_rate
         self.mu_model = None
         self.optimizer = None
+        self.fused = bool(fused)      # philox noise: the whole fitness loop through ses_openai_generation (four launches)
+        self._spare = None
 
     def _population_size(self):
         return self.offspring_num
@@ -343,8 +358,10 @@ class openai_es(_DeviceStrategy):
     def evaluate_async(self, rewards):
         """evaluate() without the read-back: best_reward comes as a PendingReward (result() waits for it)."""
         fit = self._fitness_tensor(rewards)
+        if self.noise == "philox" and self.fused:
+            return self._evaluate_fused(fit)
         _, weights = self.dev.rank_center(fit, best=self._ring.best)
-        best = self._ring.push()                  # copied to pinned memory in stream order: nothing here waits
+        best = self._ring.push()                  # copied to pinned memory on a side stream: nothing here waits
         a = self.optimizer.next_step_scale()
         opt = self.optimizer
         if self.noise == "philox":
@@ -355,6 +372,32 @@ class openai_es(_DeviceStrategy):
                                       self.mu_model, opt.m, opt.v)
         self.curr_sigma *= self.sigma_decay
         pop = self._gen_offsprings(self.agent_ids, self.mu_model, self.curr_sigma, self.offspring_num)
+        return pop, best, self.curr_sigma
+
+    def _evaluate_fused(self, fit):
+        """The same generation through ses_openai_generation: rank shaping, gradient, Adam and the next population
+        in four launches; (mu, m, v) ping-pong between two buffer triples.  Bit-identical to the step-by-step path
+        (tests/test_gpu_host_mirror.py::test_openai_fused_generation_equals_stepwise)."""
+        opt = self.optimizer
+        a = opt.next_step_scale()
+        if self._spare is None:
+            self._spare = tuple(torch.empty_like(self.mu_model) for _ in range(3))
+        state_in, state_out = (self.mu_model, opt.m, opt.v), self._spare
+        sigma = self.curr_sigma
+        self.curr_sigma *= self.sigma_decay
+        n = self.offspring_num
+        shard = self._shard(n)
+        theta = self.dev.openai_generation(fit, self.seed, self._last["gen"], self.learning_rate, sigma, a, state_in,
+                                           state_out, self.curr_sigma, self.gen, shard.first, shard.n_local,
+                                           best=self._ring.best)
+        best = self._ring.push()
+        self._spare = state_in
+        self.mu_model, opt.m, opt.v = state_out
+        opt.pi = self.mu_model
+        self._last = {"parents": self.mu_model.view(1, -1), "idx_host": self._last["idx_host"], "sigma": self.curr_sigma,
+                      "gen": self.gen, "shard": shard}
+        pop = Population(theta, shard, self.network, self.agent_ids, self.gen)
+        self.gen += 1
         return pop, best, self.curr_sigma
 
     def get_wandb_cfg(self):

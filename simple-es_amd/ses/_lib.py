@@ -63,6 +63,8 @@ SIGNATURES = {
     "ses_rollout": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "ses_rank_center": [_vp, _vp, _i32, _vp, _vp, _vp],
     "ses_es_update_philox": [_vp, _vp, _i32, _i32, _u64, _u64, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
+    "ses_openai_generation": [_vp, _vp, _i32, _u64, _u64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _u64, _i64, _i32,
+                              _vp, _vp],
     "ses_es_update_stored": [_vp, _vp, _i32, _vp, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
     "ses_elite_ids": [_vp, _vp, _i32, _i32, _vp],
     "ses_elite_select": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],

@@ -297,6 +297,27 @@ class HipES:
                                              _ptr(grad)), "ses_es_update_philox")
         return grad
 
+    def openai_generation(self, fitness, seed, gen, lr, sigma, adam_a, state_in, state_out, next_sigma, next_gen,
+                          first_row, n_rows, theta_next=None, best=None):
+        """ses_openai_generation: rank shaping + ES gradient + Adam + the next population in four launches.
+        state_in / state_out: (mu, m, v) triples of distinct float32[P] tensors.  Returns theta_next[n_rows, P]."""
+        n = fitness.shape[0]
+        self._chk(fitness, "fitness", torch.float32, (n,))
+        for name, t in zip(("mu_in", "m_in", "v_in", "mu_out", "m_out", "v_out"), tuple(state_in) + tuple(state_out)):
+            self._chk(t, name, torch.float32, (self.P,))
+        if any(a.data_ptr() == b.data_ptr() for a, b in zip(state_in, state_out)):
+            raise SesError("openai_generation: state_in and state_out must be distinct buffers")
+        self._chk(best, "best", torch.float32, (1,), optional=True)
+        if not (0 <= first_row and first_row + n_rows <= n):
+            raise SesError(f"openai_generation: rows [{first_row}, +{n_rows}) outside the population of {n}")
+        theta = (self.empty(n_rows, self.P) if theta_next is None else
+                 self._chk(theta_next, "theta_next", torch.float32, (n_rows, self.P)))
+        check(self._lib.ses_openai_generation(self._h, _ptr(fitness), int(n), int(seed), int(gen), float(lr), float(sigma),
+                                              float(adam_a), *[_ptr(t) for t in state_in], *[_ptr(t) for t in state_out],
+                                              float(next_sigma), int(next_gen), int(first_row), int(n_rows),
+                                              _ptr(theta) if n_rows else None, _ptr(best)), "ses_openai_generation")
+        return theta
+
     def es_update_stored(self, weights, eps_store, lr, sigma, adam_a, mu, m, v, want_grad=False):
         n = weights.shape[0]
         self._chk(weights, "weights", torch.float64, (n,))
