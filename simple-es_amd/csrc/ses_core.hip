@@ -118,6 +118,7 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     h->tune_gru_sequential = 0;
     h->tune_rollout_mix = 1;
     h->tune_rollout_waves8 = 1024;
+    h->tune_lander_per_wave = 0;
     *out = h;
     return SES_OK;
 }
@@ -135,12 +136,15 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"gru_ep_parallel_max", &ses_handle::tune_gru_ep_parallel_max, 0, 1 << 30},
                                  {"gru_sequential", &ses_handle::tune_gru_sequential, 0, 1},
                                  {"rollout_mix", &ses_handle::tune_rollout_mix, 0, 1},
-                                 {"rollout_waves8", &ses_handle::tune_rollout_waves8, 1, 1 << 20}};
+                                 {"rollout_waves8", &ses_handle::tune_rollout_waves8, 1, 1 << 20},
+                                 {"lander_offspring_per_wave", &ses_handle::tune_lander_per_wave, 0, 4}};
     for (const Knob &k : knobs) {
         if (std::strcmp(k.name, name) == 0) {
             SES_REQUIRE(value >= k.lo && value <= k.hi, "ses_set_tuning: %s = %d outside [%d, %d]", name, value, k.lo, k.hi);
             SES_REQUIRE(k.field != &ses_handle::tune_rollout_block || value == 64 || value == 256,
                         "ses_set_tuning: rollout_block must be 64 or 256");
+            SES_REQUIRE(k.field != &ses_handle::tune_lander_per_wave || value != 3,
+                        "ses_set_tuning: lander_offspring_per_wave must be 0, 1, 2 or 4");
             h->*(k.field) = value;
             return SES_OK;
         }

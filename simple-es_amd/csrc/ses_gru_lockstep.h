@@ -55,6 +55,9 @@ struct GruLockstep {
     gl_v2f w[3][16];         // {W_ih, W_hh}[g][j][16 kh + k]
     gl_v2f b[3];             // {b_ih, b_hh}[g][j] on the lower half, 0 on the upper half
 
+    // WITH_LDS = false: the register part only (kernels that stream the weights of several offspring through one wave
+    // reload it every step and write W2 / b2 to LDS once)
+    template <bool WITH_LDS = true>
     __device__ __forceinline__ void load(const float *__restrict__ theta, int lane, GruLockstepLds<S, A> &lds)
     {
         const int j = lane & 31, kh = lane >> 5;
@@ -73,12 +76,14 @@ struct GruLockstep {
             }
             b[g] = kh ? gl_v2f{0.0f, 0.0f} : gl_v2f{pbi[g * H + j], pbh[g * H + j]};
         }
-        p = pbh + 3 * H;
-        if (kh == 0) {
+        if constexpr (WITH_LDS) {
+            p = pbh + 3 * H;
+            if (kh == 0) {
 #pragma unroll
-            for (int o = 0; o < A; ++o) lds.w2[o][j] = p[o * H + j];
+                for (int o = 0; o < A; ++o) lds.w2[o][j] = p[o * H + j];
+            }
+            if (lane < A) lds.b2[lane] = p[A * H + lane];
         }
-        if (lane < A) lds.b2[lane] = p[A * H + lane];
     }
 
     // One time step for the episodes [0, 2*NP) of the batch.  hreg[p] is this lane's hidden unit for the episode

@@ -28,6 +28,7 @@ struct ses_handle {
     int tune_gru_sequential;       // 1: episode-after-episode GRU kernels only
     int tune_rollout_mix;          // 0: no mixed LPE-8 / LPE-4 split for mid-sized CartPole MLP populations
     int tune_rollout_waves8;       // LPE-8 waves of the mixed split
+    int tune_lander_per_wave;      // offspring per wave of the lockstep lander rollout: 0 = by population size, 1 / 2 / 4
 };
 
 namespace ses {

@@ -344,7 +344,7 @@ struct LanderLs {
     };
     __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u, int slot)
     {
-        __shared__ float terrain[4][GM_EB][LL_TERRAIN_ROW];    // one terrain row per (wave, episode slot)
+        __shared__ float terrain[4][32][LL_TERRAIN_ROW];       // one terrain row per (wave, env slot); slot < 32
         ll_reset(s.st, u, terrain[threadIdx.x >> 6][slot]);
     }
     __device__ static __forceinline__ void observe(const State &s, float (&obs)[S]) { ll_obs(s.st, obs); }
@@ -452,6 +452,115 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_rollout_gru_lockstep(const fl
         }
 #undef SES_LS_CASE
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lockstep GRU rollout with G offspring per wave, for envs whose step dwarfs the policy (the Box2D-style lander: ~20 000
+// instructions per world step against ~600 for the GRU step of five episodes).  An env step costs a wave the same
+// number of issue slots whether 5 or 40 of its lanes carry a live env, so the wave takes the envs of G offspring:
+// lane l owns env (offspring (l >> 3) % G, episode l & 7), one call of the env step serves G x E envs.  The policy is
+// evaluated offspring after offspring by all 64 lanes as in the one-offspring kernel (same arithmetic, same lane roles);
+// the weights cannot all stay in registers, so each offspring's slice (~110 floats per lane) is re-read from its theta
+// row (L2) before its GRU step -- ~27 KB per offspring and time step, 11 GB per C3 generation, next to 20 000
+// instructions of solver per step.  Hidden states stay in registers (G x NP) and in the per-offspring LDS block.
+// Measured (C3, 4096 offspring x 5 episodes): see DESIGN.md section 4.
+template <typename EnvT, int G, int NP, bool ODD>
+__device__ __forceinline__ void gru_lockstep_multi_batch(const TanhEntry *tanh_tab, GruLockstepLds<EnvT::S, EnvT::A> *lds,
+                                                         const float *__restrict__ theta, int P, int row0, int n_rows,
+                                                         int lane, int nb, const float *__restrict__ init,
+                                                         int init_per_offspring, int E, int max_step, uint32_t obs_mask,
+                                                         double *__restrict__ ep_return, int32_t *__restrict__ ep_steps)
+{
+    constexpr int S = EnvT::S, A = EnvT::A;
+    const int slot = lane & 7, rep = lane >> 3, gl = rep % G;
+    const int my_row_raw = row0 + gl;
+    const bool row_valid = my_row_raw < n_rows;
+    const int my_row = row_valid ? my_row_raw : n_rows - 1;
+    const bool owner_valid = slot < nb && row_valid;
+    typename EnvT::State st;
+    EnvT::reset(st, init + ((size_t)(init_per_offspring ? my_row : 0) * E + (slot < nb ? slot : 0)) * EnvT::INIT_W, gl * 8 + slot);
+    float hreg[G][NP];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) hreg[g][p] = 0.0f;                           // GymEnvModel.reset()
+        const int row_g = row0 + g < n_rows ? row0 + g : n_rows - 1;
+        GruLockstep<S, A> net;
+        net.template load<true>(theta + (size_t)row_g * P, lane, lds[g]);         // W2 / b2 -> LDS (the registers are dropped)
+        if (lane < 32) {
+#pragma unroll
+            for (int e = 0; e < GL_EB; ++e) lds[g].ah[e][lane][1] = 0.0f;
+        }
+    }
+    wave_lds_sync();
+    double ret = 0.0;
+    int steps = 0;
+    bool alive = true;
+    for (int t = 0; t < max_step; ++t) {
+        if (__ballot(alive & owner_valid) == 0ull) break;
+        float obs[S];
+        EnvT::observe(st, obs);
+        float logits[A];
+#pragma unroll
+        for (int o = 0; o < A; ++o) logits[o] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int row_g = row0 + g < n_rows ? row0 + g : n_rows - 1;
+            GruLockstep<S, A> net;
+            net.template load<false>(theta + (size_t)row_g * P, lane, lds[g]);
+            if (rep == g) {                                                       // the first replica group of offspring g
+#pragma unroll
+                for (int k = 0; k < S; ++k) lds[g].obs[slot][k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
+            }
+            wave_lds_sync();
+            net.template step<NP, ODD>(tanh_tab, lds[g], hreg[g], lane);
+            float lg[A];
+            net.logits_of(lds[g], lane, lg);
+#pragma unroll
+            for (int o = 0; o < A; ++o) logits[o] = gl == g ? lg[o] : logits[o];
+        }
+        bool term;
+        const bool freeze = !(alive & owner_valid);
+        const float r = EnvT::step(st, logits, tanh_tab, freeze, term);
+        const int nsteps = steps + 1;
+        const bool finished = term | (nsteps >= max_step);
+        ret = alive ? ret + (double)r : ret;
+        steps = alive ? nsteps : steps;
+        alive = alive & !finished;
+    }
+    if (owner_valid && rep < G) {
+        if (ep_return) ep_return[(size_t)my_row * E + slot] = ret;
+        if (ep_steps) ep_steps[(size_t)my_row * E + slot] = steps;
+    }
+}
+
+template <typename EnvT, int G>
+__global__ __launch_bounds__(256, 2) void k_rollout_gru_lockstep_multi(const float *__restrict__ theta,
+                                                                    const float *__restrict__ init, int init_per_offspring,
+                                                                    int n_rows, int E, int P, int max_step,
+                                                                    uint32_t obs_mask, double *__restrict__ ep_return,
+                                                                    int32_t *__restrict__ ep_steps)
+{
+    __shared__ TanhEntry tanh_tab[SES_TANH_N];
+    __shared__ __attribute__((aligned(16))) GruLockstepLds<EnvT::S, EnvT::A> ldsv[4][G];
+    stage_tanh_table(tanh_tab);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + wave) * G;
+    if (row0 >= n_rows) return;                       // (no workgroup-level synchronisation after the table staging)
+#define SES_LSM_CASE(NP_, ODD_)                                                                                          \
+    gru_lockstep_multi_batch<EnvT, G, NP_, ODD_>(tanh_tab, ldsv[wave], theta, P, row0, n_rows, lane, E, init,              \
+                                                 init_per_offspring, E, max_step, obs_mask, ep_return, ep_steps)
+    switch (E) {                                      // E <= GL_EB (the launcher checks)
+        case 1: SES_LSM_CASE(1, true); break;
+        case 2: SES_LSM_CASE(1, false); break;
+        case 3: SES_LSM_CASE(2, true); break;
+        case 4: SES_LSM_CASE(2, false); break;
+        case 5: SES_LSM_CASE(3, true); break;
+        case 6: SES_LSM_CASE(3, false); break;
+        case 7: SES_LSM_CASE(4, true); break;
+        default: SES_LSM_CASE(4, false); break;
+    }
+#undef SES_LSM_CASE
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -912,6 +1021,19 @@ static bool gru_episode_parallel(const ses_handle *h, long long episodes)
 // ses_set_tuning "gru_sequential" = 1 selects the episode-after-episode GRU kernels
 static bool gru_sequential(const ses_handle *h) { return h->tune_gru_sequential != 0; }
 
+// Offspring per wave of the lockstep lander rollout (k_rollout_gru_lockstep_multi): as many as leave about two waves
+// per SIMD (2048 on the chip), all resident at once.  The env step is a sequential 20 000-instruction routine: a
+// rollout costs (steps of the longest episode) x (time of one wave-step), a wave-step costs the same for 5 or 20 envs,
+// and two waves on a SIMD fill each other's dependency stalls.  Measured, C3 (4096 offspring x 5 episodes, one box):
+// 1 offspring per wave 44.8 ms, 2: 31.8 ms, 4: 35.9 ms (one wave per SIMD, and with 20 envs in a wave most steps have
+// some env on the ground, i.e. run the contact rows).
+// ses_set_tuning "lander_offspring_per_wave": 0 = this rule, 1 / 2 / 4 = forced.
+static int lander_offspring_per_wave(const ses_handle *h, int n_rows)
+{
+    if (h->tune_lander_per_wave) return h->tune_lander_per_wave;
+    return n_rows >= 6144 ? 4 : (n_rows >= 1536 ? 2 : 1);
+}
+
 static void launch_cartpole_mlp(const ses_handle *h, const float *theta, const float *init, int per, int n_rows,
                                 int mode, double *epr, int32_t *ep_steps)
 {
@@ -970,6 +1092,14 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
                                h->obs_mask, epr, ep_steps, 1);
         else if (h->cfg.gru && !gru_sequential(h) && h->cfg.eval_ep_num >= gru_mfma_min_e(h))
             hipLaunchKernelGGL((k_rollout_gru_mfma<LanderLs, false>), dim3(ceil_div(n_rows, 4)), dim3(256), 0,
+                               h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
+                               h->cfg.max_step, h->obs_mask, epr, ep_steps);
+        else if (h->cfg.gru && !gru_sequential(h) && h->cfg.eval_ep_num <= GL_EB && lander_offspring_per_wave(h, n_rows) == 4)
+            hipLaunchKernelGGL((k_rollout_gru_lockstep_multi<LanderLs, 4>), dim3(ceil_div(n_rows, 16)), dim3(256), 0,
+                               h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
+                               h->cfg.max_step, h->obs_mask, epr, ep_steps);
+        else if (h->cfg.gru && !gru_sequential(h) && h->cfg.eval_ep_num <= GL_EB && lander_offspring_per_wave(h, n_rows) == 2)
+            hipLaunchKernelGGL((k_rollout_gru_lockstep_multi<LanderLs, 2>), dim3(ceil_div(n_rows, 8)), dim3(256), 0,
                                h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
                                h->cfg.max_step, h->obs_mask, epr, ep_steps);
         else if (h->cfg.gru && !gru_sequential(h))

@@ -139,8 +139,10 @@ def test_lander_gru_rollout_on_the_matrix_cores_bit_exact():
 
 @pytest.mark.parametrize("knobs", [{"SES_TUNING": "gru_ep_parallel_max=0"},
                                    {"SES_TUNING": "gru_ep_parallel_max=0,gru_mfma_min_e=1"},
-                                   {"SES_TUNING": "gru_ep_parallel_max=1000000"}],
-                         ids=["lockstep", "mfma", "episode_parallel"])
+                                   {"SES_TUNING": "gru_ep_parallel_max=1000000"},
+                                   {"SES_TUNING": "gru_ep_parallel_max=0,lander_offspring_per_wave=2"},
+                                   {"SES_TUNING": "gru_ep_parallel_max=0,lander_offspring_per_wave=4"}],
+                         ids=["lockstep", "mfma", "episode_parallel", "lander_2_per_wave", "lander_4_per_wave"])
 def test_gru_parity_suites_on_every_kernel_path(knobs):
     """ses_rollout picks the GRU kernel from the population size and episode count: one wave per (offspring, episode)
     up to 4096 episodes, the VALU lockstep kernel above, the MFMA kernel from 12 episodes.  The fixtures and most
