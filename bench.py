@@ -321,7 +321,8 @@ def run_rank(args):
     job.generations(args.warmup)
     times = timed_blocks(job, args.steps, max(args.blocks, 1), barrier, dist, world)
     weak = summarise(job, args.steps, times)
-    comm_rank, comm_world, rccl_version = job.loop.dev.comm_info()
+    from ses.parallel import comm_info
+    comm_rank, comm_world, rccl_version = comm_info(job.loop.dev)
     weak.update(job.phases())
     weak["rccl_ranks"] = comm_world
 
@@ -357,7 +358,7 @@ def run_rank(args):
                 t = timed_blocks(j, x_steps, x_blocks, barrier, dist, world)
                 rec = summarise(j, x_steps, t)
                 rec.update(j.phases())
-                rec["rccl_ranks"] = j.loop.dev.comm_info()[1]
+                rec["rccl_ranks"] = comm_info(j.loop.dev)[1]
                 result[key] = rec
                 del j
             except Exception as exc:                                 # the headline line must still be printed

@@ -63,6 +63,41 @@ def test_raw_abi_comm_error_paths():
     assert lib.ses_destroy(h) == 0
 
 
+SHARED = textwrap.dedent("""
+    import os, sys, torch
+    sys.path[:0] = [%r, %r]
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from ses import HipES
+    from ses import parallel
+    a = HipES("CartPole-v1", 4, 2, True, False)
+    b = HipES("CartPole-v1", 4, 2, True, True)
+    assert parallel.attach_comm(a, allow_single=True) and parallel.attach_comm(b, allow_single=True)
+    assert a._comm_owner is b._comm_owner and a._comm_owner is not a          # one communicator per process, on its own handle
+    assert parallel.comm_info(a)[:2] == (0, 1) and a.comm_info()[1] == 0
+    x = torch.rand(4096, device="cuda")
+    assert torch.equal(a._comm_owner.allgather_fitness(x), x)
+    a.close(); b.close()                                                       # the owner outlives the handles that use it
+    assert torch.equal(parallel._COMM[(0, 1)].allgather_fitness(x), x)
+    dist.destroy_process_group()
+    print("shared-communicator ok")
+""")
+
+
+def test_one_shared_communicator_per_process(tmp_path):
+    """attach_comm: the RCCL communicator lives on a dedicated handle shared by every loop of the process (a 1-rank nccl
+    process group stands in for the multi-GPU launch on this 1-GPU box)."""
+    script = tmp_path / "s.py"
+    script.write_text(SHARED % (ROOT, SRC))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {**os.environ, "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "shared-communicator ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 WORKER = textwrap.dedent("""
     import contextlib, io, os, sys
     import numpy as np, torch
@@ -81,7 +116,8 @@ WORKER = textwrap.dedent("""
                "strategy": {"name": name, "init_sigma": 0.5, "sigma_decay": 0.99, "learning_rate": 0.05,
                             "elite_num": 8, "offspring_num": n, "seed": 5}}
         loop = builder.build_loop(cfg, 4, 1, 3, False, 10 ** 9)
-        assert loop.dev.comm_info()[1] == (world if world > 1 else 0)
+        from ses.parallel import comm_info
+        assert comm_info(loop.dev)[1] == (world if world > 1 else 0)
         fits = []
         orig = loop.rollout
         loop.rollout = lambda pop, _o=orig: (fits.append(_o(pop).cpu().numpy().copy()) or torch.from_numpy(fits[-1]).cuda())
