@@ -124,7 +124,7 @@ struct World {
     Manifold mf[D::NB - D::FIRST_SOLVED][D::NSLOT];   // of the bodies whose contacts are solved (index b - FIRST_SOLVED)
     float sleep_time[D::NB];
     bool ground_contact[D::NB];
-    bool game_over, awake, first_step;
+    bool game_over, awake;
     float fx, fy;                    // b2Body::m_force of body 0 (ApplyForceToCenter), cleared after a step
 };
 
@@ -217,7 +217,6 @@ B2_FN void collide_edge_polygon(const Poly &P, const Xf &xf, const float (&wx)[6
     int poly_index = -1;
     float poly_sep = -FLT_BIG;
     bool poly_early = false;
-    const float perpx = -mny, perpy = mnx;
     B2_UNROLL
     for (int i = 0; i < 6; ++i) {
         if (i < n && !poly_early) {
@@ -228,9 +227,9 @@ B2_FN void collide_edge_polygon(const Poly &P, const Xf &xf, const float (&wx)[6
             if (s > radius) {
                 poly_index = i; poly_sep = s; poly_early = true;
             } else {
-                // adjacency: both branches compare against the same limit for an isolated edge
+                // adjacency: Box2D picks the upper or the lower limit by the side of `perp` the normal lies on; for an
+                // isolated edge the two limits coincide
                 const bool skip = ((nx - limx) * mnx + (ny - limy) * mny) < -ANGULAR_SLOP;
-                (void)perpx; (void)perpy;
                 if (!skip && s > poly_sep) { poly_index = i; poly_sep = s; }
             }
         }
@@ -834,7 +833,6 @@ B2_FN void world_step(World<D> &w, const T &terr, float dt)
         }
     }
     if (min_sleep >= TIME_TO_SLEEP && position_solved) w.awake = false;
-    w.first_step = false;
 }
 
 }  // namespace b2l

@@ -184,7 +184,7 @@ B2_FN void lander_reset_state(LanderEnv &e, const float *u)
         J.motor_speed = j == 0 ? -0.3f : 0.3f;       // +0.3 * i
         J.max_torque = LL_LEG_SPRING_TORQUE;
     }
-    w.game_over = false; w.awake = true; w.first_step = true;
+    w.game_over = false; w.awake = true;
     w.fx = 2000.0f * u[0] - 1000.0f;                 // np_random.uniform(-INITIAL_RANDOM, INITIAL_RANDOM)
     w.fy = 2000.0f * u[1] - 1000.0f;
     e.prev_shaping = 0.0f;

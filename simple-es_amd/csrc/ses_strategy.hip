@@ -250,9 +250,10 @@ __global__ __launch_bounds__(256) void k_es_grad_partial(const double *__restric
     if (threadIdx.x < 4) partial[(size_t)blockIdx.y * P4 + 4 * q + threadIdx.x] = red[threadIdx.x][0];
 }
 
+// (mu, m, v) may be updated in place (mu_out == mu ...) or into other buffers
 __global__ __launch_bounds__(256) void k_es_apply(const float *__restrict__ partial, int chunks, int P, int P4,
-                                                  float update_factor, double adam_a, float *__restrict__ mu,
-                                                  float *__restrict__ m, float *__restrict__ v,
+                                                  float update_factor, double adam_a, const float *mu, const float *m,
+                                                  const float *v, float *mu_out, float *m_out, float *v_out,
                                                   float *__restrict__ grad_out)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void k_es_apply(const float *__restrict__ part
     if (grad_out) grad_out[p] = g;
     float muv = mu[p], mv = m[p], vv = v[p];
     adam_apply(g, adam_a, muv, mv, vv);
-    mu[p] = muv; m[p] = mv; v[p] = vv;
+    mu_out[p] = muv; m_out[p] = mv; v_out[p] = vv;
 }
 
 // ---- the openai_es fitness loop in four launches (ses_openai_generation) -----------------------------------------
@@ -309,6 +310,29 @@ __global__ __launch_bounds__(256) void k_es_grad_partial_ranked(const int32_t *_
         __syncthreads();
     }
     if (threadIdx.x < 4) partial[(size_t)blockIdx.y * P4 + 4 * q + threadIdx.x] = red[threadIdx.x][0];
+}
+
+constexpr int ES_FUSED_APPLY_MAX_CHUNKS = 8;   // populations up to 8192 rows
+
+// k_perturb for the openai_es population shape: global row 0 = mu, every other row mu + sigma * eps
+__global__ __launch_bounds__(256) void k_perturb_openai(const float *__restrict__ mu, float sigma, uint64_t seed,
+                                                        uint64_t gen, long long first_row, int n_rows, int P, int quads,
+                                                        float *__restrict__ theta)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n_rows * quads) return;
+    const int i = (int)(t / quads);
+    const int q = (int)(t - (long long)i * quads);
+    const int lim = P - 4 * q < 4 ? P - 4 * q : 4;
+    float *dst = theta + (size_t)i * P + 4 * q;
+    const long long row = first_row + i;
+    if (row == 0) {
+        for (int l = 0; l < lim; ++l) dst[l] = mu[4 * q + l];
+        return;
+    }
+    float z[4];
+    normal4(seed, gen, (uint32_t)row, (uint32_t)q, z);
+    for (int l = 0; l < lim; ++l) dst[l] = fma_(sigma, z[l], mu[4 * q + l]);
 }
 
 // one thread = (row of this rank's shard, parameter quad): Adam for the quad, then the row's perturbation of the new mu
@@ -539,7 +563,7 @@ int ses_es_update_philox(ses_handle *h, const double *weights, int32_t n, int32_
     hipLaunchKernelGGL(k_es_grad_partial, dim3(quads, chunks), dim3(256), 0, h->stream, weights, n, skip_row0, seed, gen,
                        P4, partial);
     hipLaunchKernelGGL(k_es_apply, dim3(ceil_div(h->P, 256)), dim3(256), 0, h->stream, partial, chunks, h->P, P4,
-                       (float)uf, adam_a, mu, m, v, grad_out);
+                       (float)uf, adam_a, mu, m, v, mu, m, v, grad_out);
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;
 }
@@ -583,10 +607,22 @@ int ses_openai_generation(ses_handle *h, const float *fitness, int32_t n, uint64
     uf *= -1.0;
     hipLaunchKernelGGL(k_es_grad_partial_ranked, dim3(quads, chunks), dim3(256), 0, h->stream, rank, fitness, n, 1, seed,
                        gen, P4, partial, best);
-    const long long threads = (long long)(n_rows > 0 ? n_rows : 1) * quads;
-    hipLaunchKernelGGL(k_es_apply_perturb, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, partial, chunks, h->P, P4,
-                       (float)uf, adam_a, mu_in, m_in, v_in, mu_out, m_out, v_out, next_sigma, seed, next_gen,
-                       (long long)first_row, n_rows, quads, theta_next);
+    if (chunks <= ES_FUSED_APPLY_MAX_CHUNKS) {
+        const long long threads = (long long)(n_rows > 0 ? n_rows : 1) * quads;
+        hipLaunchKernelGGL(k_es_apply_perturb, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, partial, chunks, h->P,
+                           P4, (float)uf, adam_a, mu_in, m_in, v_in, mu_out, m_out, v_out, next_sigma, seed, next_gen,
+                           (long long)first_row, n_rows, quads, theta_next);
+    } else {
+        // large populations: every perturbation thread re-adding `chunks` partials would cost O(n * chunks) L2 reads
+        // (65 536 offspring: 1 ms); one small launch finishes the update, the perturbation reads the new mu
+        hipLaunchKernelGGL(k_es_apply, dim3(ceil_div(h->P, 256)), dim3(256), 0, h->stream, partial, chunks, h->P, P4,
+                           (float)uf, adam_a, mu_in, m_in, v_in, mu_out, m_out, v_out, (float *)nullptr);
+        if (n_rows > 0) {
+            const long long threads = (long long)n_rows * quads;
+            hipLaunchKernelGGL(k_perturb_openai, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, mu_out, next_sigma,
+                               seed, next_gen, (long long)first_row, n_rows, h->P, quads, theta_next);
+        }
+    }
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;
 }

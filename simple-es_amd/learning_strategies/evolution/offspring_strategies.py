@@ -73,16 +73,14 @@ class PendingReward:
 
 
 class _ReadbackRing:
-    """`depth` (device float, pinned host float, events) slots reused round-robin (the loop keeps at most two
-    generations in flight).  `best` is the device slot the current generation's kernels write; push() copies it to
-    the host on a SIDE stream, behind an event recorded on the launch stream: the next generation's kernels are
-    not queued behind a 5 us device-to-host copy."""
+    """`depth` (device float, pinned host float, event) slots reused round-robin (the loop keeps at most two
+    generations in flight).  `best` is the device slot the current generation's kernels write; push() queues its copy
+    to the host behind them.  (A side stream for the copy was tried: the generation method got no faster and
+    ESLoop.run(), which waits for the previous generation's value every iteration, got 15 % slower -- reverted.)"""
 
     def __init__(self, device, depth=4):
         self.dev_slots = [torch.zeros(1, dtype=torch.float32, device=device) for _ in range(depth)]
-        self.slots = [(torch.zeros(1, dtype=torch.float32).pin_memory(), torch.cuda.Event(), torch.cuda.Event())
-                      for _ in range(depth)]
-        self.side = torch.cuda.Stream(device=device)
+        self.slots = [(torch.zeros(1, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(depth)]
         self.k = 0
 
     @property
@@ -90,15 +88,12 @@ class _ReadbackRing:
         return self.dev_slots[self.k]
 
     def push(self):
-        host, produced, copied = self.slots[self.k]
+        host, event = self.slots[self.k]
         src = self.dev_slots[self.k]
         self.k = (self.k + 1) % len(self.slots)
-        produced.record()                               # on the launch stream, after the kernel that wrote `src`
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(produced)
-            host.copy_(src, non_blocking=True)
-            copied.record()
-        return PendingReward(host, copied)
+        host.copy_(src, non_blocking=True)
+        event.record()
+        return PendingReward(host, event)
 
 
 class _DeviceStrategy(BaseOffspringStrategy):
