@@ -91,6 +91,13 @@ int ses_sync(ses_handle *h);
  * "rollout_waves8" (1024), "rollout_block" (64 | 256), "lander_offspring_per_wave" (0 = by population size | 1 | 2 | 4).
  * The library itself reads no environment variable. */
 int ses_set_tuning(ses_handle *h, const char *name, int32_t value);
+/* Timing without events: from now on the last kernel of every ses_rollout (the episode mean: end of the rollout phase)
+ * and every perturbation launch (ses_perturb, ses_perturb_host_noise, ses_openai_generation: the next population is
+ * being written) of this handle stores the GPU's constant-rate real-time counter (100 MHz, common to all kernels,
+ * streams and handles of the device) into *dst -- device-visible memory, e.g. pinned host memory the caller polls.
+ * NULL switches it off.  Replaces the HIP events around `p.map(RolloutWorker, ...)` / `strategy.evaluate` that
+ * loop.py:64-86 times with time.time(): an event costs the launch stream ~4.7 us, a stamp nothing. */
+int ses_set_stamp(ses_handle *h, uint64_t *dst);
 const char *ses_last_error(void);
 const char *ses_version(void);
 /* number of parameters P of GymEnvModel(S, A, _, gru)  (networks/neural_network.py:9-18) */

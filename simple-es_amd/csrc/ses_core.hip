@@ -152,6 +152,13 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
     return ses::set_error(SES_ERR_INVALID_ARG, "ses_set_tuning: unknown knob '%s'", name);
 }
 
+int ses_set_stamp(ses_handle *h, uint64_t *dst)
+{
+    SES_REQUIRE(h, "ses_set_stamp: null handle");
+    h->stamp = (unsigned long long *)dst;
+    return SES_OK;
+}
+
 int ses_destroy(ses_handle *h)
 {
     if (!h) return SES_OK;

@@ -28,10 +28,16 @@ struct ses_handle {
     int tune_gru_sequential;       // 1: episode-after-episode GRU kernels only
     int tune_rollout_mix;          // 0: no mixed LPE-8 / LPE-4 split for mid-sized CartPole MLP populations
     int tune_rollout_waves8;       // LPE-8 waves of the mixed split
+    // ses_set_stamp: where the next stamped launch of this handle writes the GPU real-time counter (or null)
+    unsigned long long *stamp;
     int tune_lander_per_wave;      // offspring per wave of the lockstep lander rollout: 0 = by population size, 1 / 2 / 4
 };
 
 namespace ses {
+
+// the constant-rate (100 MHz) real-time counter shared by the whole GPU: timestamps taken inside kernels are
+// comparable across kernels, streams and handles
+__device__ __forceinline__ unsigned long long real_time() { return wall_clock64(); }
 
 int set_error(int code, const char *fmt, ...);
 

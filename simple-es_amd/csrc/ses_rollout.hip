@@ -820,9 +820,11 @@ __global__ __launch_bounds__(64) void k_rollout_spread_mlp(const float *__restri
     if (valid && sub == 0) ep_return[env] = ret;
 }
 
-__global__ void k_fitness_mean(const double *__restrict__ ep_return, int n_rows, int E, float *__restrict__ fitness)
+__global__ void k_fitness_mean(const double *__restrict__ ep_return, int n_rows, int E, float *__restrict__ fitness,
+                               unsigned long long *__restrict__ stamp)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (stamp && i == 0) *stamp = real_time();                          // end of the rollout phase (ses_set_stamp)
     if (i >= n_rows) return;
     double total = 0.0;
     for (int e = 0; e < E; ++e) total += ep_return[(size_t)i * E + e];
@@ -1202,7 +1204,7 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
         launch_cartpole_mlp(h, theta, init, init_per_offspring, n_rows, mode, epr, ep_steps);
     }
     hipLaunchKernelGGL(k_fitness_mean, dim3(ceil_div(n_rows, 256)), dim3(256), 0, h->stream, epr, n_rows,
-                       h->cfg.eval_ep_num, fitness);
+                       h->cfg.eval_ep_num, fitness, h->stamp);
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;
 }

@@ -12,9 +12,10 @@ __global__ __launch_bounds__(256) void k_perturb(const float *__restrict__ paren
                                                  const int32_t *__restrict__ parent_idx,
                                                  const int32_t *__restrict__ row_ids, float sigma, uint64_t seed,
                                                  uint64_t gen, long long first_row, int n_rows, int P, int quads,
-                                                 float *__restrict__ theta)
+                                                 float *__restrict__ theta, unsigned long long *__restrict__ stamp)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (stamp && t == 0) *stamp = real_time();                           // ses_set_stamp: the next population is being written
     if (t >= (long long)n_rows * quads) return;
     const int i = (int)(t / quads);
     const int q = (int)(t - (long long)i * quads);
@@ -50,9 +51,11 @@ __global__ __launch_bounds__(256) void k_perturb_host_noise(const float *__restr
                                                             const int32_t *__restrict__ parent_idx,
                                                             const double *__restrict__ eps64, double sigma,
                                                             int n_rows, int P, float *__restrict__ theta,
-                                                            float *__restrict__ eps_store)
+                                                            float *__restrict__ eps_store,
+                                                            unsigned long long *__restrict__ stamp)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (stamp && t == 0) *stamp = real_time();
     if (t >= (long long)n_rows * P) return;
     const int i = (int)(t / P);
     const int p = (int)(t - (long long)i * P);
@@ -317,9 +320,10 @@ constexpr int ES_FUSED_APPLY_MAX_CHUNKS = 8;   // populations up to 8192 rows
 // k_perturb for the openai_es population shape: global row 0 = mu, every other row mu + sigma * eps
 __global__ __launch_bounds__(256) void k_perturb_openai(const float *__restrict__ mu, float sigma, uint64_t seed,
                                                         uint64_t gen, long long first_row, int n_rows, int P, int quads,
-                                                        float *__restrict__ theta)
+                                                        float *__restrict__ theta, unsigned long long *__restrict__ stamp)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (stamp && t == 0) *stamp = real_time();
     if (t >= (long long)n_rows * quads) return;
     const int i = (int)(t / quads);
     const int q = (int)(t - (long long)i * quads);
@@ -343,9 +347,11 @@ __global__ __launch_bounds__(256) void k_es_apply_perturb(const float *__restric
                                                           const float *__restrict__ v_in, float *__restrict__ mu_out,
                                                           float *__restrict__ m_out, float *__restrict__ v_out,
                                                           float sigma, uint64_t seed, uint64_t gen, long long first_row,
-                                                          int n_rows, int quads, float *__restrict__ theta)
+                                                          int n_rows, int quads, float *__restrict__ theta,
+                                                          unsigned long long *__restrict__ stamp)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (stamp && t == 0) *stamp = real_time();
     if (t >= (long long)(n_rows > 0 ? n_rows : 1) * quads) return;
     const int i = (int)(t / quads);
     const int q = (int)(t - (long long)i * quads);
@@ -467,7 +473,7 @@ int ses_perturb(ses_handle *h, const float *parents, const int32_t *parent_idx, 
     const int quads = (h->P + 3) / 4;
     const long long threads = (long long)n_rows * quads;
     hipLaunchKernelGGL(k_perturb, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, parents, parent_idx, row_ids,
-                       sigma, seed, gen, (long long)first_row, n_rows, h->P, quads, theta);
+                       sigma, seed, gen, (long long)first_row, n_rows, h->P, quads, theta, h->stamp);
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;
 }
@@ -493,7 +499,7 @@ int ses_perturb_host_noise(ses_handle *h, const float *parents, const int32_t *p
     SES_HIP_TRY(hipSetDevice(h->cfg.device));
     const long long threads = (long long)n_rows * h->P;
     hipLaunchKernelGGL(k_perturb_host_noise, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, parents,
-                       parent_idx, eps64, sigma, n_rows, h->P, theta, eps_store);
+                       parent_idx, eps64, sigma, n_rows, h->P, theta, eps_store, h->stamp);
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;
 }
@@ -611,7 +617,7 @@ int ses_openai_generation(ses_handle *h, const float *fitness, int32_t n, uint64
         const long long threads = (long long)(n_rows > 0 ? n_rows : 1) * quads;
         hipLaunchKernelGGL(k_es_apply_perturb, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, partial, chunks, h->P,
                            P4, (float)uf, adam_a, mu_in, m_in, v_in, mu_out, m_out, v_out, next_sigma, seed, next_gen,
-                           (long long)first_row, n_rows, quads, theta_next);
+                           (long long)first_row, n_rows, quads, theta_next, h->stamp);
     } else {
         // large populations: every perturbation thread re-adding `chunks` partials would cost O(n * chunks) L2 reads
         // (65 536 offspring: 1 ms); one small launch finishes the update, the perturbation reads the new mu
@@ -620,7 +626,7 @@ int ses_openai_generation(ses_handle *h, const float *fitness, int32_t n, uint64
         if (n_rows > 0) {
             const long long threads = (long long)n_rows * quads;
             hipLaunchKernelGGL(k_perturb_openai, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, mu_out, next_sigma,
-                               seed, next_gen, (long long)first_row, n_rows, h->P, quads, theta_next);
+                               seed, next_gen, (long long)first_row, n_rows, h->P, quads, theta_next, h->stamp);
         }
     }
     SES_HIP_TRY(hipGetLastError());

@@ -45,8 +45,11 @@ class ESLoop(BaseESLoop):
         self.env_variant = getattr(env, "variant", None)     # e.g. "box2d-restated": third-party physics restated, unpinned
         self.history = []
         self._metrics = None
-        self._events = None
+        self._stamps = None
         self._ev_k = 0
+        self._prefetched = None     # ((generation, first row, rows), init states, event) drawn ahead on the side stream
+        self._side = None
+        self._side_dev = None
 
         # logs/<env>/<timestamp>[_k]: the reference's makedirs (loop.py:40-47) raises when two loops start in the same
         # second; here the second one gets a suffix instead of silently sharing the directory.  Only rank 0 writes.
@@ -71,18 +74,47 @@ class ESLoop(BaseESLoop):
                          pomdp=env.pomdp, max_step=env.horizon, eval_ep_num=eval_ep_num,
                          n_agents=getattr(env, "n_agents", 1), physics64=getattr(env, "physics64", False))
         attach_comm(self.dev)      # multi-GPU: the fitness all-gather runs on this handle's RCCL communicator
-        self._events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
+        # [end of the rollout phase, start of the kernel that writes the next population] in ticks of the GPU's 100 MHz
+        # real-time counter, one pinned pair per generation in flight
+        self._stamps = [torch.zeros(2, dtype=torch.int64).pin_memory() for _ in range(4)]
+        self._prev_tail = 0
+
+    def _init_states(self, gen, shard):
+        if self.shared_init:                       # common random numbers: every offspring sees the same resets
+            return self.dev.init_states_uniform(self.seed_env, gen, 0, 1, shared=True)[0]
+        init = self.dev.init_states_uniform(self.seed_env, gen, shard.first, max(shard.n_local, 1))   # reference: independent resets
+        return init[: shard.n_local].contiguous() if shard.n_local != init.shape[0] else init
 
     # the rollout phase of one generation: Population -> float32[N] fitness (identical on every rank)
     def rollout(self, population):
         shard = population.shard
-        if self.shared_init:                       # common random numbers: every offspring sees the same resets
-            init = self.dev.init_states_uniform(self.seed_env, population.gen, 0, 1, shared=True)[0]
-        else:                                      # reference behaviour: independent resets per offspring
-            init = self.dev.init_states_uniform(self.seed_env, population.gen, shard.first, max(shard.n_local, 1))
-            if shard.n_local != init.shape[0]:
-                init = init[: shard.n_local].contiguous()
+        # The resets of a generation depend on (env seed, generation counter) only, so those of generation g + 1 are
+        # drawn on a side stream while rollout g runs (a 4 us kernel that would otherwise sit between the last kernel of
+        # one generation and the rollout of the next); the launch stream waits for the side stream's event, long done.
+        pre = self._prefetched
+        if pre is not None and pre[0] == (population.gen, shard.first, shard.n_local):
+            torch.cuda.current_stream().wait_event(pre[2])
+            init = pre[1]
+        else:
+            init = self._init_states(population.gen, shard)
         local = self.dev.rollout(population.theta, init, mode=self.mode) if shard.n_local else self.dev.empty(0)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev.device)
+            self._side_dev = HipES(self.env.name, self.network.num_state, self.network.num_action,
+                                   self.network.discrete_action, self.network.use_gru, pomdp=self.env.pomdp,
+                                   max_step=self.env.horizon, eval_ep_num=self.eval_ep_num,
+                                   n_agents=getattr(self.env, "n_agents", 1), stream=self._side)
+        done = torch.cuda.Event()
+        with torch.cuda.stream(self._side):                                   # allocation and launch on the side stream
+            if self.shared_init:
+                nxt = self._side_dev.init_states_uniform(self.seed_env, population.gen + 1, 0, 1, shared=True)[0]
+            else:
+                nxt = self._side_dev.init_states_uniform(self.seed_env, population.gen + 1, shard.first, max(shard.n_local, 1))
+                if shard.n_local != nxt.shape[0]:
+                    nxt = nxt[: shard.n_local].contiguous()
+            done.record()
+        nxt.record_stream(torch.cuda.current_stream())                        # consumed by the next rollout on the launch stream
+        self._prefetched = ((population.gen + 1, shard.first, shard.n_local), nxt, done)
         return shard.allgather_fitness(local, dev=self.dev)
 
     def generation(self, offsprings):
@@ -90,27 +122,42 @@ class ESLoop(BaseESLoop):
         the next population -- WITHOUT waiting for the GPU.  Returns (next offspring group, best reward as a
         PendingReward, sigma, (event before, event after the rollout phase)).  run() is a loop of this plus the
         reference's logging; bench.py times exactly this method."""
-        ev0, ev1 = self._events[self._ev_k]
-        self._ev_k = (self._ev_k + 1) % len(self._events)
-        ev0.record()
-        results = self.rollout(offsprings)
-        ev1.record()
+        # timing without events (an event costs the launch stream ~5 us, three per generation were 5 % of it): the last
+        # kernel of the rollout phase and the kernel that writes the next population stamp the GPU's real-time counter
+        # into a pinned slot (ses_set_stamp); _report reads the slots of a finished generation
+        stamp = self._stamps[self._ev_k]
+        self._ev_k = (self._ev_k + 1) % len(self._stamps)
+        stamp.zero_()
+        self.dev.set_stamp(stamp[0:1])
         strategy = self.offspring_strategy
+        sdev = getattr(strategy, "dev", None)
+        if sdev is not None:
+            sdev.set_stamp(stamp[1:2])
+        results = self.rollout(offsprings)
         if hasattr(strategy, "evaluate_async"):
             offsprings, best, curr_sigma = strategy.evaluate_async(results)
         else:                                      # a user strategy with the reference's synchronous evaluate() only
             offsprings, value, curr_sigma = strategy.evaluate(results)
             best = _Ready(value)
-        return offsprings, best, curr_sigma, (ev0, ev1)
+        return offsprings, best, curr_sigma, stamp
 
-    def _report(self, ep_num, best, curr_sigma, events, start_time, rank0):
+    def _report(self, ep_num, best, curr_sigma, stamp, start_time, rank0):
         """The reference's per-generation bookkeeping (loop.py:85-99) for a generation whose results are in."""
         best_reward = best.result()                # waits for THAT generation only; the next one is already queued
         now = time.time()
         consumed_time = now - max(start_time, self._last_report)    # generations overlap: time between completions
         self._last_report = now
-        rollout_consumed_time = events[0].elapsed_time(events[1]) * 1e-3   # GPU time of the rollout phase (HIP events)
-        eval_consumed_time = max(consumed_time - rollout_consumed_time, 0.0)
+        spins = 0
+        while int(stamp[1]) == 0 and spins < 200000:               # written a few us after the best reward
+            spins += 1
+        t_roll, t_tail = int(stamp[0]), int(stamp[1])
+        if t_roll and t_tail and self._prev_tail and t_roll > self._prev_tail:
+            rollout_consumed_time = (t_roll - self._prev_tail) * 1e-8      # GPU time of the rollout phase (100 MHz ticks)
+            eval_consumed_time = max((t_tail - t_roll) * 1e-8, 0.0)        # GPU time of strategy.evaluate up to the next population
+        else:                                      # first generation of a run / a strategy without a device handle
+            eval_consumed_time = max((t_tail - t_roll) * 1e-8, 0.0) if t_roll and t_tail else 0.0
+            rollout_consumed_time = max(consumed_time - eval_consumed_time, 0.0)
+        self._prev_tail = t_tail
         self.history.append((best_reward, curr_sigma))
         self.ep5_rewards.append(best_reward)
         if not rank0:

@@ -59,41 +59,51 @@ class Population:
 
 
 class PendingReward:
-    """best_reward of a generation, read back without stalling the thread that enqueues the next one: the float is
-    copied into pinned host memory behind the kernels that produce it, result() waits for that copy alone."""
+    """best_reward of a generation, read back without stalling the thread that enqueues the next one and without an
+    event in the launch stream: the kernel that finds the maximum stores it straight into pinned host memory, which
+    the host pre-set to NaN when it enqueued the generation; result() polls until the value is there (falling back to
+    a stream synchronisation if it does not appear -- a NaN maximum would mean NaN returns)."""
 
-    def __init__(self, host, event):
-        self._host, self._event, self._value = host, event, None
+    def __init__(self, host):
+        self._host, self._value = host, None
 
     def result(self):
         if self._value is None:
-            self._event.synchronize()
-            self._value = float(self._host[0])
+            v = float(self._host[0])
+            spins = 0
+            while v != v:
+                spins += 1
+                if spins > 2000000:                     # ~seconds: give up polling, wait for the device
+                    torch.cuda.synchronize()
+                    v = float(self._host[0])
+                    break
+                v = float(self._host[0])
+            self._value = v
         return self._value
 
 
 class _ReadbackRing:
-    """`depth` (device float, pinned host float, event) slots reused round-robin (the loop keeps at most two
-    generations in flight).  `best` is the device slot the current generation's kernels write; push() queues its copy
-    to the host behind them.  (A side stream for the copy was tried: the generation method got no faster and
-    ESLoop.run(), which waits for the previous generation's value every iteration, got 15 % slower -- reverted.)"""
+    """`depth` pinned host floats reused round-robin (the loop keeps at most two generations in flight).  `best` is the
+    slot the current generation's kernels write -- host memory the GPU can store to, so neither a copy nor an event sits
+    in the launch stream (a queued 4-byte device-to-host copy cost ~10 us of stream time per generation, an event ~5)."""
 
     def __init__(self, device, depth=4):
-        self.dev_slots = [torch.zeros(1, dtype=torch.float32, device=device) for _ in range(depth)]
-        self.slots = [(torch.zeros(1, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(depth)]
+        self.slots = [torch.full((1,), float("nan"), dtype=torch.float32).pin_memory() for _ in range(depth)]
         self.k = 0
 
     @property
     def best(self):
-        return self.dev_slots[self.k]
+        return self.slots[self.k]
+
+    def arm(self):
+        """call BEFORE enqueueing the kernels that write `best`: marks the slot as pending"""
+        self.slots[self.k][0] = float("nan")
+        return self.slots[self.k]
 
     def push(self):
-        host, event = self.slots[self.k]
-        src = self.dev_slots[self.k]
+        host = self.slots[self.k]
         self.k = (self.k + 1) % len(self.slots)
-        host.copy_(src, non_blocking=True)
-        event.record()
-        return PendingReward(host, event)
+        return PendingReward(host)
 
 
 class _DeviceStrategy(BaseOffspringStrategy):
@@ -259,7 +269,7 @@ class simple_genetic(_DeviceStrategy):
     def evaluate_async(self, rewards):
         """evaluate() without the read-back: best_reward comes as a PendingReward (result() waits for it)."""
         fit = self._fitness_tensor(rewards)
-        rank, _ = self.dev.rank_center(fit, want_weights=False, best=self._ring.best)
+        rank, _ = self.dev.rank_center(fit, want_weights=False, best=self._ring.arm())
         best = self._ring.push()
         self.elite_models, _ = self._select_elites(rank, self.elite_num)
         pop = self._gen_offsprings(self.agent_ids, self.elite_models, self.elite_num, self.offspring_num,
@@ -305,7 +315,7 @@ class simple_evolution(_DeviceStrategy):
     def evaluate_async(self, rewards):
         """evaluate() without the read-back: best_reward comes as a PendingReward (result() waits for it)."""
         fit = self._fitness_tensor(rewards)
-        rank, _ = self.dev.rank_center(fit, want_weights=False, best=self._ring.best)
+        rank, _ = self.dev.rank_center(fit, want_weights=False, best=self._ring.arm())
         best = self._ring.push()
         # the reference sums the elites IN PLACE into elite[0]; an elite that is the same object as elite[0]
         # (slots 0 and 1 while they alias) doubles the running sum instead of adding its own value: the flags and
@@ -355,8 +365,8 @@ class openai_es(_DeviceStrategy):
         fit = self._fitness_tensor(rewards)
         if self.noise == "philox" and self.fused:
             return self._evaluate_fused(fit)
-        _, weights = self.dev.rank_center(fit, best=self._ring.best)
-        best = self._ring.push()                  # copied to pinned memory on a side stream: nothing here waits
+        _, weights = self.dev.rank_center(fit, best=self._ring.arm())
+        best = self._ring.push()
         a = self.optimizer.next_step_scale()
         opt = self.optimizer
         if self.noise == "philox":
@@ -384,7 +394,7 @@ class openai_es(_DeviceStrategy):
         shard = self._shard(n)
         theta = self.dev.openai_generation(fit, self.seed, self._last["gen"], self.learning_rate, sigma, a, state_in,
                                            state_out, self.curr_sigma, self.gen, shard.first, shard.n_local,
-                                           best=self._ring.best)
+                                           best=self._ring.arm())
         best = self._ring.push()
         self._spare = state_in
         self.mu_model, opt.m, opt.v = state_out

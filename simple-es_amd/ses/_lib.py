@@ -50,6 +50,7 @@ SIGNATURES = {
     "ses_destroy": [_vp],
     "ses_sync": [_vp],
     "ses_set_tuning": [_vp, ctypes.c_char_p, _i32],
+    "ses_set_stamp": [_vp, _vp],
     "ses_last_error": [],
     "ses_version": [],
     "ses_param_count": [_i32, _i32, _i32],

@@ -49,7 +49,7 @@ class HipES:
 
     def __init__(self, env_name="CartPole-v1", num_state=4, num_action=2, discrete_action=True, gru=False,
                  pomdp=False, max_step=500, eval_ep_num=5, device=None, lanes_per_env=0, n_agents=1,
-                 physics64=False):
+                 physics64=False, stream=None):
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise SesError("no HIP device visible to torch: the simple-es hot path needs an MI355X "
@@ -78,7 +78,7 @@ class HipES:
         self._lib = lib
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            self.stream = torch.cuda.current_stream(self.device)
+            self.stream = torch.cuda.current_stream(self.device) if stream is None else stream   # the handle's launch stream
             check(lib.ses_create(ctypes.byref(cfg), ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(self._h)),
                   "ses_create")
         # test hook: SES_TUNING="gru_ep_parallel_max=0,gru_mfma_min_e=1" forces a kernel path for every handle of the
@@ -90,6 +90,15 @@ class HipES:
     def set_tuning(self, name, value):
         """ses_set_tuning: choose among the result-identical rollout kernels (include/ses.h lists the knobs)."""
         check(self._lib.ses_set_tuning(self._h, name.encode(), int(value)), "ses_set_tuning")
+
+    def set_stamp(self, dst):
+        """ses_set_stamp: dst = pinned host (or device) int64[1] tensor that receives the GPU real-time counter at the end
+        of this handle's next rollouts / perturbation launches; None switches the stamping off."""
+        if dst is not None and not (isinstance(dst, torch.Tensor) and dst.dtype == torch.int64 and dst.numel() >= 1 and
+                                    (dst.is_pinned() if dst.device.type == "cpu" else dst.device == self.device)):
+            raise SesError("set_stamp: expected a pinned host or device int64 tensor")
+        self._stamp_keepalive = dst
+        check(self._lib.ses_set_stamp(self._h, _ptr(dst)), "ses_set_stamp")
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -119,6 +128,17 @@ class HipES:
         if tuple(t.shape) != tuple(shape):
             raise SesError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
         return t
+
+    def _chk_best(self, best):
+        """float32[1] that receives max(fitness): a tensor on the handle's device, or PINNED host memory -- the kernel
+        then stores the value straight into host-visible memory (no device-to-host copy queued between the kernels)."""
+        if best is None:
+            return None
+        if isinstance(best, torch.Tensor) and best.device.type == "cpu":
+            if not (best.is_pinned() and best.dtype == torch.float32 and best.numel() == 1 and best.is_contiguous()):
+                raise SesError("best: a host tensor must be pinned float32[1]")
+            return best
+        return self._chk(best, "best", torch.float32, (1,))
 
     def _check_parent_idx(self, parent_idx, K):
         """-K <= parent_idx < K, or raise.  The check reads the tensor back (a device sync), so its result is cached --
@@ -279,7 +299,7 @@ class HipES:
         tensor that receives max(fitness) in the same launch."""
         n = fitness.shape[0]
         self._chk(fitness, "fitness", torch.float32, (n,))
-        self._chk(best, "best", torch.float32, (1,), optional=True)
+        self._chk_best(best)
         rank = self.empty(n, dtype=torch.int32)
         weights = self.empty(n, dtype=torch.float64) if want_weights else None
         check(self._lib.ses_rank_center(self._h, _ptr(fitness), int(n), _ptr(rank), _ptr(weights), _ptr(best)),
@@ -307,7 +327,7 @@ class HipES:
             self._chk(t, name, torch.float32, (self.P,))
         if any(a.data_ptr() == b.data_ptr() for a, b in zip(state_in, state_out)):
             raise SesError("openai_generation: state_in and state_out must be distinct buffers")
-        self._chk(best, "best", torch.float32, (1,), optional=True)
+        self._chk_best(best)
         if not (0 <= first_row and first_row + n_rows <= n):
             raise SesError(f"openai_generation: rows [{first_row}, +{n_rows}) outside the population of {n}")
         theta = (self.empty(n_rows, self.P) if theta_next is None else

@@ -112,3 +112,49 @@ def test_env_object_protocol_and_pomdp_mask():
         s, r, done, _ = env.step({"0": np.array([1.0, 0.0, 0.3, -0.3], np.float32)})
         t += 1
     assert t == 20                                                  # truncated by max_step (gym_wrapper.py:37-39)
+
+
+def test_free_flight_conserves_momentum():
+    """No engines, no contacts: the joints exchange impulses between hull and legs only, so the total linear momentum
+    changes by gravity alone (m g dt per step) and the angular momentum about the common centre of mass stays put --
+    a check of the solver's impulse bookkeeping that needs no Box2D."""
+    sim = co.LanderSim()
+    sim.reset(np.array([0.9, 0.2] + [0.3] * 12 + [0.11, 0.22], np.float32))
+    m = np.array([1 / float.fromhex("0x1.a930b8p-3"), 1 / float.fromhex("0x1.c1fffcp+3"), 1 / float.fromhex("0x1.c1fffcp+3")])
+    inertia = np.array([1 / float.fromhex("0x1.46948ep+0"), 1 / float.fromhex("0x1.172e92p+9"), 1 / float.fromhex("0x1.172e92p+9")])
+
+    def momenta():
+        b, info = sim.debug()
+        b = b.astype(np.float64)
+        assert info["contact_points"] == 0
+        p = (m[:, None] * b[:, 3:5]).sum(0)
+        com = (m[:, None] * b[:, 0:2]).sum(0) / m.sum()
+        r = b[:, 0:2] - com
+        L = (inertia * b[:, 5]).sum() + (m * (r[:, 0] * b[:, 4] - r[:, 1] * b[:, 3])).sum()
+        return p, L
+
+    p0, L0 = momenta()
+    for k in range(1, 31):
+        sim.step(0.0, 0.0)
+        p, L = momenta()
+        assert abs(p[0] - p0[0]) < 2e-4 * k ** 0.5 + 1e-4, (k, p, p0)                   # float32 solver noise only
+        assert abs((p[1] - p0[1]) - (-10.0 * 0.02 * k * m.sum())) < 1e-3, (k, p, p0)
+        assert abs(L - L0) < 5e-3, (k, L, L0)                                          # |L| ~ 1: 0.5 % over 30 steps
+
+
+def test_resting_contact_is_quiet():
+    """After a soft landing the legs carry the hull: penetration stays within Box2D's slop (the hull origin sits
+    LEG_DOWN above the pad to a few mm), velocities die out and the island falls asleep instead of jittering."""
+    rng = np.random.RandomState(11)
+    sim = co.LanderSim()
+    obs = sim.reset(rng.rand(16).astype(np.float32))
+    done, t, speeds = False, 0, []
+    while not done and t < 600:
+        obs, r, done = sim.step(*heuristic(obs))
+        t += 1
+        if obs[6] and obs[7]:
+            b, _ = sim.debug()
+            speeds.append(float(np.abs(b[:, 3:6]).max()))
+    assert done and r == 100.0                                     # asleep: every body below the sleep tolerances for 0.5 s
+    assert len(speeds) > 25 and max(speeds[-20:]) < 0.02
+    assert abs(obs[1]) < 0.01 and abs(obs[4]) < 0.05
