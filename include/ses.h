@@ -177,8 +177,9 @@ int ses_rank_center(ses_handle *h, const float *fitness, int32_t n, int32_t *ran
 
 /* ---- K5: ES gradient + Adam (offspring_strategies.py:400-416, optimizers.py:13-24,42-57) ---- */
 /* One generation's fitness loop of openai_es (offspring_strategies.py:380-419 followed by _gen_offsprings :284-328) in
- * four launches: rank keys, rank count (sort + search above 8192), ES-gradient partials with the rank-centring weights
- * formed inline, Adam + Philox perturbation of the next population.  Bit-identical to ses_rank_center +
+ * three launches (up to 8192 offspring): counting rank with the keys formed inline, ES-gradient partials with the
+ * rank-centring weights formed inline and Adam applied by the last workgroup, Philox perturbation of the next population
+ * (larger populations: keys, tile sort, search, gradient, update, perturbation).  Bit-identical to ses_rank_center +
  * ses_es_update_philox(skip_row0 = 1) + ses_perturb called one after the other (tests/test_gpu_host_mirror.py).
  *   fitness[n]: the gathered fitness of the evaluated population (noise generation `gen`, std `sigma`);
  *   (mu, m, v)_in -> (mu, m, v)_out: distinct float32[P] buffers, the caller ping-pongs them;

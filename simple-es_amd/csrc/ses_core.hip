@@ -43,6 +43,8 @@ int ensure_reduce_scratch(ses_handle *h, size_t bytes)
     }
     h->red_scratch = nullptr;
     h->red_cap = 0;
+    h->rank_zeroed = nullptr;                       // whatever was known about the old buffer's contents is gone
+    h->counter_armed = nullptr;
     SES_HIP_TRY(hipMalloc(&h->red_scratch, want));
     h->red_cap = want;
     return SES_OK;

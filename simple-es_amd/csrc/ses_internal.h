@@ -30,6 +30,10 @@ struct ses_handle {
     int tune_rollout_waves8;       // LPE-8 waves of the mixed split
     // ses_set_stamp: where the next stamped launch of this handle writes the GPU real-time counter (or null)
     unsigned long long *stamp;
+    // ses_openai_generation: the rank vector in red_scratch that is known to be zero (left so by the update kernel)
+    int32_t *rank_zeroed;
+    int rank_zeroed_n;
+    unsigned int *counter_armed;   // the last-block ticket counter in red_scratch that is known to be zero
     int tune_lander_per_wave;      // offspring per wave of the lockstep lander rollout: 0 = by population size, 1 / 2 / 4
 };
 

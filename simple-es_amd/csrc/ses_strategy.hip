@@ -130,6 +130,38 @@ __global__ __launch_bounds__(256) void k_rank_count(const unsigned long long *__
     if (i < n && count) atomicAdd(&rank[i], count);
 }
 
+// The same count with the keys formed on the fly from the fitness values (ses_openai_generation): the competitor's
+// fitness is wave-uniform, so its key is built with scalar instructions next to the scalar load; rank[] must be zero on
+// entry (the update kernel of the previous generation leaves it so).
+__device__ __forceinline__ unsigned long long rank_key(uint32_t u, uint32_t index)
+{
+    u = u == 0x80000000u ? 0u : u;                                   // -0 -> +0 (what `fit + 0.0f` does in k_rank_keys)
+    const uint32_t ordered = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)ordered << 32) | (unsigned long long)index;
+}
+
+__global__ __launch_bounds__(256) void k_rank_count_fitness(const float *__restrict__ fit, int n, int jt,
+                                                            int32_t *__restrict__ rank)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j0 = blockIdx.y * jt;
+    const int lim = n - j0 < jt ? n - j0 : jt;
+    const int ic = i < n ? i : n - 1;
+    const unsigned long long ki = rank_key(f2u(fit[ic]), (uint32_t)ic);
+    const uint32_t *__restrict__ fj = reinterpret_cast<const uint32_t *>(fit) + j0;   // uniform base: scalar loads below
+    int count = 0;
+    int k = 0;
+    for (; k + 16 <= lim; k += 16) {
+        uint32_t c[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[e] = fj[k + e];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) count += (rank_key(c[e], (uint32_t)(j0 + k + e)) > ki) ? 1 : 0;
+    }
+    for (; k < lim; ++k) count += (rank_key(fj[k], (uint32_t)(j0 + k)) > ki) ? 1 : 0;
+    if (i < n && count) atomicAdd(&rank[i], count);
+}
+
 // Large populations (n > RANK_SORT_MIN): sort tiles of RANK_TILE keys in LDS (bitonic network), then every
 // offspring binary-searches each sorted tile for the number of larger keys.  O(n log^2 T + n (n/T) log T)
 // instead of O(n^2).  Keys are distinct (index in the low
@@ -275,16 +307,28 @@ __global__ __launch_bounds__(256) void k_es_apply(const float *__restrict__ part
 // four small launches after the rollout instead of seven:
 //   * the rank-centring weight of a row is a closed form of its rank: formed where it is used (stage 1 of the gradient)
 //     instead of being written and re-read; the thread that meets rank 0 also reports best = max(fitness);
-//   * Adam's update of (mu, m, v) -- P parameters -- is recomputed by every thread of the perturbation kernel for the
-//     four parameters it perturbs (chunk partials added in the same ascending order), so the next population is written
-//     by the launch that finishes the update; the threads of the shard's first row store the new (mu, m, v).  Old and
-//     new vectors are distinct buffers (the caller ping-pongs): no thread can read a value another one has updated.
+//   * Adam's update of (mu, m, v) -- P parameters -- is done by the gradient kernel's last workgroup (chunk partials
+//     added in the same ascending order), so no launch exists for it; old and new vectors are distinct buffers (the
+//     caller ping-pongs).  (An earlier form recomputed the update in every thread of the perturbation kernel: that
+//     kernel then took as long as the two it replaced, and O(n x chunks) reads made it 1 ms at 65 536 offspring.)
+//   * the keys of the counting rank are formed inside the count from the fitness values, the rank vector is cleared for
+//     the next generation by the perturbation kernel: no key kernel, no memset.
+// final == true: the workgroup that finishes last (a ticket from an atomic counter) adds the chunk partials in ascending
+// order and applies Adam for all P parameters -- (mu, m, v)_in -> (mu, m, v)_out -- so that the launch that follows only
+// has to perturb the new mu (the "last block done" reduction: writers fence before taking their ticket, the finishing
+// workgroup fences before it reads; it also re-arms the counter).
+template <bool FINAL>
 __global__ __launch_bounds__(256) void k_es_grad_partial_ranked(const int32_t *__restrict__ rank,
                                                                 const float *__restrict__ fitness, int n, int skip_row0,
                                                                 uint64_t seed, uint64_t gen, int P4,
-                                                                float *__restrict__ partial, float *__restrict__ best)
+                                                                float *partial, float *__restrict__ best,
+                                                                unsigned int *counter, int chunks, int P,
+                                                                float update_factor, double adam_a, const float *mu_in,
+                                                                const float *m_in, const float *v_in, float *mu_out,
+                                                                float *m_out, float *v_out)
 {
     __shared__ float red[4][256];
+    __shared__ unsigned int ticket;
     const int q = blockIdx.x;
     const int row0 = blockIdx.y * ES_CHUNK;
     const int row1 = row0 + ES_CHUNK < n ? row0 + ES_CHUNK : n;
@@ -313,17 +357,37 @@ __global__ __launch_bounds__(256) void k_es_grad_partial_ranked(const int32_t *_
         __syncthreads();
     }
     if (threadIdx.x < 4) partial[(size_t)blockIdx.y * P4 + 4 * q + threadIdx.x] = red[threadIdx.x][0];
+    if (!FINAL) return;
+    // ---- last workgroup done: finish the update ----
+    if (threadIdx.x < 4) __threadfence();                              // this workgroup's partials are visible device-wide
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = atomicAdd(counter, 1u);
+    __syncthreads();
+    if (ticket != gridDim.x * gridDim.y - 1) return;
+    __threadfence();                                                   // ... before anybody else's are read
+    if (threadIdx.x == 0) *counter = 0u;                               // armed for the next generation
+    for (int p = threadIdx.x; p < P; p += 256) {
+        float sum = __hip_atomic_load(partial + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // device-coherent read
+        for (int c = 1; c < chunks; ++c) sum = sum + __hip_atomic_load(partial + (size_t)c * P4 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float g = sum * update_factor;                           // offspring_strategies.py:414
+        float muv = mu_in[p], mv = m_in[p], vv = v_in[p];
+        adam_apply(g, adam_a, muv, mv, vv);
+        mu_out[p] = muv; m_out[p] = mv; v_out[p] = vv;
+    }
 }
 
-constexpr int ES_FUSED_APPLY_MAX_CHUNKS = 8;   // populations up to 8192 rows
+constexpr int ES_FUSED_APPLY_MAX_CHUNKS = 8;   // populations up to 8192 rows take the three-launch form
 
 // k_perturb for the openai_es population shape: global row 0 = mu, every other row mu + sigma * eps
 __global__ __launch_bounds__(256) void k_perturb_openai(const float *__restrict__ mu, float sigma, uint64_t seed,
                                                         uint64_t gen, long long first_row, int n_rows, int P, int quads,
-                                                        float *__restrict__ theta, unsigned long long *__restrict__ stamp)
+                                                        float *__restrict__ theta, unsigned long long *__restrict__ stamp,
+                                                        int32_t *__restrict__ rank_to_clear, int n_clear)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (stamp && t == 0) *stamp = real_time();
+    // the rank vector has been consumed by the gradient kernel: leave it zeroed for the next generation's count
+    for (long long i = t; i < n_clear; i += (long long)gridDim.x * blockDim.x) rank_to_clear[i] = 0;
     if (t >= (long long)n_rows * quads) return;
     const int i = (int)(t / quads);
     const int q = (int)(t - (long long)i * quads);
@@ -337,46 +401,6 @@ __global__ __launch_bounds__(256) void k_perturb_openai(const float *__restrict_
     float z[4];
     normal4(seed, gen, (uint32_t)row, (uint32_t)q, z);
     for (int l = 0; l < lim; ++l) dst[l] = fma_(sigma, z[l], mu[4 * q + l]);
-}
-
-// one thread = (row of this rank's shard, parameter quad): Adam for the quad, then the row's perturbation of the new mu
-// (global row 0 is the unperturbed mu: openai_es member 0, offspring_strategies.py:300-304)
-__global__ __launch_bounds__(256) void k_es_apply_perturb(const float *__restrict__ partial, int chunks, int P, int P4,
-                                                          float update_factor, double adam_a,
-                                                          const float *__restrict__ mu_in, const float *__restrict__ m_in,
-                                                          const float *__restrict__ v_in, float *__restrict__ mu_out,
-                                                          float *__restrict__ m_out, float *__restrict__ v_out,
-                                                          float sigma, uint64_t seed, uint64_t gen, long long first_row,
-                                                          int n_rows, int quads, float *__restrict__ theta,
-                                                          unsigned long long *__restrict__ stamp)
-{
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (stamp && t == 0) *stamp = real_time();
-    if (t >= (long long)(n_rows > 0 ? n_rows : 1) * quads) return;
-    const int i = (int)(t / quads);
-    const int q = (int)(t - (long long)i * quads);
-    const int lim = P - 4 * q < 4 ? P - 4 * q : 4;
-    float mu_new[4];
-    for (int l = 0; l < lim; ++l) {
-        const int p = 4 * q + l;
-        float sum = partial[p];
-        for (int c = 1; c < chunks; ++c) sum = sum + partial[(size_t)c * P4 + p];
-        const float g = sum * update_factor;                              // offspring_strategies.py:414
-        float muv = mu_in[p], mv = m_in[p], vv = v_in[p];
-        adam_apply(g, adam_a, muv, mv, vv);
-        mu_new[l] = muv;
-        if (i == 0) { mu_out[p] = muv; m_out[p] = mv; v_out[p] = vv; }
-    }
-    if (n_rows <= 0) return;                                              // a rank without rows still keeps (mu, m, v)
-    float *dst = theta + (size_t)i * P + 4 * q;
-    const long long row = first_row + i;
-    if (row == 0) {
-        for (int l = 0; l < lim; ++l) dst[l] = mu_new[l];
-        return;
-    }
-    float z[4];
-    normal4(seed, gen, (uint32_t)row, (uint32_t)q, z);
-    for (int l = 0; l < lim; ++l) dst[l] = fma_(sigma, z[l], mu_new[l]);
 }
 
 // Reference-order accumulation over stored (mu + eps) rows: one thread per parameter, sequential over
@@ -532,6 +556,8 @@ int ses_rank_center(ses_handle *h, const float *fitness, int32_t n, int32_t *ran
     const size_t key_bytes = (sizeof(unsigned long long) * (size_t)n + 255) / 256 * 256;
     const int rc = ensure_reduce_scratch(h, key_bytes + sizeof(unsigned long long) * (size_t)tiles * RANK_TILE);
     if (rc != SES_OK) return rc;
+    h->rank_zeroed = nullptr;                       // this call lays the scratch out differently from ses_openai_generation
+    h->counter_armed = nullptr;
     unsigned long long *keys = (unsigned long long *)h->red_scratch;
     hipLaunchKernelGGL(k_rank_keys, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, fitness, n, keys, rank);
     if (n > RANK_SORT_MIN) {
@@ -565,6 +591,8 @@ int ses_es_update_philox(ses_handle *h, const double *weights, int32_t n, int32_
     const size_t key_bytes = (sizeof(unsigned long long) * (size_t)n + 255) / 256 * 256;
     const int rc = ensure_reduce_scratch(h, key_bytes + sizeof(float) * (size_t)chunks * P4);
     if (rc != SES_OK) return rc;
+    h->rank_zeroed = nullptr;
+    h->counter_armed = nullptr;
     float *partial = (float *)((char *)h->red_scratch + key_bytes);
     hipLaunchKernelGGL(k_es_grad_partial, dim3(quads, chunks), dim3(256), 0, h->stream, weights, n, skip_row0, seed, gen,
                        P4, partial);
@@ -595,38 +623,64 @@ int ses_openai_generation(ses_handle *h, const float *fitness, int32_t n, uint64
     const size_t key_bytes = (sizeof(unsigned long long) * (size_t)n + 255) / 256 * 256;
     const size_t sorted_bytes = sizeof(unsigned long long) * (size_t)tiles * RANK_TILE;
     const size_t rank_bytes = (sizeof(int32_t) * (size_t)n + 255) / 256 * 256;
-    const int rc = ensure_reduce_scratch(h, key_bytes + sorted_bytes + rank_bytes + sizeof(float) * (size_t)chunks * P4);
+    const int rc = ensure_reduce_scratch(h, key_bytes + sorted_bytes + rank_bytes + sizeof(float) * (size_t)chunks * P4 + 256);
     if (rc != SES_OK) return rc;
     unsigned long long *keys = (unsigned long long *)h->red_scratch;
     unsigned long long *sorted = (unsigned long long *)((char *)h->red_scratch + key_bytes);
     int32_t *rank = (int32_t *)((char *)h->red_scratch + key_bytes + sorted_bytes);
     float *partial = (float *)((char *)h->red_scratch + key_bytes + sorted_bytes + rank_bytes);
-    hipLaunchKernelGGL(k_rank_keys, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, fitness, n, keys, rank);
-    if (n > RANK_SORT_MIN) {
-        hipLaunchKernelGGL(k_rank_tile_sort, dim3(tiles), dim3(RANK_TILE / 2), 0, h->stream, keys, n, sorted);
-        hipLaunchKernelGGL(k_rank_search, dim3(ceil_div(n, 256), tiles), dim3(256), 0, h->stream, keys, sorted, n, rank);
+    // Small populations whose update runs in the fused kernel: keys formed inside the count (one launch less); the rank
+    // vector is zero on entry -- cleared by that fused kernel at the end of the previous call, by a memset the first time
+    // (or whenever the scratch moved or the population size changed).
+    const bool fused_count = n <= RANK_SORT_MIN && chunks <= ES_FUSED_APPLY_MAX_CHUNKS;
+    if (fused_count) {
+        if (h->rank_zeroed != rank || h->rank_zeroed_n != n) {
+            SES_HIP_TRY(hipMemsetAsync(rank, 0, sizeof(int32_t) * (size_t)n, h->stream));
+            h->rank_zeroed = rank;
+            h->rank_zeroed_n = n;
+        }
+        hipLaunchKernelGGL(k_rank_count_fitness, dim3(ceil_div(n, 256), ceil_div(n, jt)), dim3(256), 0, h->stream, fitness,
+                           n, (int)jt, rank);
     } else {
-        hipLaunchKernelGGL(k_rank_count, dim3(ceil_div(n, 256), ceil_div(n, jt)), dim3(256), 0, h->stream, keys, n,
-                           (int)jt, rank);
+        h->rank_zeroed = nullptr;
+        hipLaunchKernelGGL(k_rank_keys, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, fitness, n, keys, rank);
+        if (n > RANK_SORT_MIN) {
+            hipLaunchKernelGGL(k_rank_tile_sort, dim3(tiles), dim3(RANK_TILE / 2), 0, h->stream, keys, n, sorted);
+            hipLaunchKernelGGL(k_rank_search, dim3(ceil_div(n, 256), tiles), dim3(256), 0, h->stream, keys, sorted, n, rank);
+        } else {
+            hipLaunchKernelGGL(k_rank_count, dim3(ceil_div(n, 256), ceil_div(n, jt)), dim3(256), 0, h->stream, keys, n,
+                               (int)jt, rank);
+        }
     }
     double uf = lr / ((double)n * sigma);            // offspring_strategies.py:406-408
     uf *= -1.0;
-    hipLaunchKernelGGL(k_es_grad_partial_ranked, dim3(quads, chunks), dim3(256), 0, h->stream, rank, fitness, n, 1, seed,
-                       gen, P4, partial, best);
-    if (chunks <= ES_FUSED_APPLY_MAX_CHUNKS) {
+    unsigned int *counter = (unsigned int *)((char *)partial + sizeof(float) * (size_t)chunks * P4);
+    if (fused_count) {
+        // small populations: the gradient kernel's last workgroup finishes the update, the next launch perturbs the new
+        // mu and clears the rank vector for the next generation
+        if (h->counter_armed != counter) {
+            SES_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int), h->stream));
+            h->counter_armed = counter;
+        }
+        hipLaunchKernelGGL((k_es_grad_partial_ranked<true>), dim3(quads, chunks), dim3(256), 0, h->stream, rank, fitness, n, 1,
+                           seed, gen, P4, partial, best, counter, chunks, h->P, (float)uf, adam_a, mu_in, m_in, v_in, mu_out,
+                           m_out, v_out);
         const long long threads = (long long)(n_rows > 0 ? n_rows : 1) * quads;
-        hipLaunchKernelGGL(k_es_apply_perturb, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, partial, chunks, h->P,
-                           P4, (float)uf, adam_a, mu_in, m_in, v_in, mu_out, m_out, v_out, next_sigma, seed, next_gen,
-                           (long long)first_row, n_rows, quads, theta_next, h->stamp);
+        hipLaunchKernelGGL(k_perturb_openai, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, mu_out, next_sigma, seed,
+                           next_gen, (long long)first_row, n_rows, h->P, quads, theta_next, h->stamp, rank, n);
     } else {
-        // large populations: every perturbation thread re-adding `chunks` partials would cost O(n * chunks) L2 reads
-        // (65 536 offspring: 1 ms); one small launch finishes the update, the perturbation reads the new mu
+        // large populations: a separate small launch finishes the update (every perturbation thread re-adding `chunks`
+        // partials would cost O(n * chunks) L2 reads: 65 536 offspring, 1 ms)
+        hipLaunchKernelGGL((k_es_grad_partial_ranked<false>), dim3(quads, chunks), dim3(256), 0, h->stream, rank, fitness, n, 1,
+                           seed, gen, P4, partial, best, counter, chunks, h->P, (float)uf, adam_a, mu_in, m_in, v_in, mu_out,
+                           m_out, v_out);
         hipLaunchKernelGGL(k_es_apply, dim3(ceil_div(h->P, 256)), dim3(256), 0, h->stream, partial, chunks, h->P, P4,
                            (float)uf, adam_a, mu_in, m_in, v_in, mu_out, m_out, v_out, (float *)nullptr);
         if (n_rows > 0) {
             const long long threads = (long long)n_rows * quads;
             hipLaunchKernelGGL(k_perturb_openai, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, mu_out, next_sigma,
-                               seed, next_gen, (long long)first_row, n_rows, h->P, quads, theta_next, h->stamp);
+                               seed, next_gen, (long long)first_row, n_rows, h->P, quads, theta_next, h->stamp,
+                               (int32_t *)nullptr, 0);
         }
     }
     SES_HIP_TRY(hipGetLastError());

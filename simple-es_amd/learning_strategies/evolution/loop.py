@@ -78,6 +78,7 @@ class ESLoop(BaseESLoop):
         # real-time counter, one pinned pair per generation in flight
         self._stamps = [torch.zeros(2, dtype=torch.int64).pin_memory() for _ in range(4)]
         self._prev_tail = 0
+        self._tail_stamped = False
 
     def _init_states(self, gen, shard):
         if self.shared_init:                       # common random numbers: every offspring sees the same resets
@@ -131,7 +132,8 @@ class ESLoop(BaseESLoop):
         self.dev.set_stamp(stamp[0:1])
         strategy = self.offspring_strategy
         sdev = getattr(strategy, "dev", None)
-        if sdev is not None:
+        self._tail_stamped = sdev is not None and hasattr(sdev, "set_stamp")
+        if self._tail_stamped:
             sdev.set_stamp(stamp[1:2])
         results = self.rollout(offsprings)
         if hasattr(strategy, "evaluate_async"):
@@ -148,7 +150,7 @@ class ESLoop(BaseESLoop):
         consumed_time = now - max(start_time, self._last_report)    # generations overlap: time between completions
         self._last_report = now
         spins = 0
-        while int(stamp[1]) == 0 and spins < 200000:               # written a few us after the best reward
+        while self._tail_stamped and int(stamp[1]) == 0 and spins < 200000:   # written a few us after the best reward
             spins += 1
         t_roll, t_tail = int(stamp[0]), int(stamp[1])
         if t_roll and t_tail and self._prev_tail and t_roll > self._prev_tail:
