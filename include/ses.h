@@ -88,7 +88,8 @@ int ses_sync(ses_handle *h);
 /* Development / test hook: which of the (result-identical) rollout kernels a handle picks.  Every kernel evaluates the
  * same canonical arithmetic, so no setting changes a result; the defaults are the measured crossovers.  Knobs:
  * "gru_ep_parallel_max" (default 4096), "gru_mfma_min_e" (12), "gru_sequential" (0), "rollout_mix" (1),
- * "rollout_waves8" (1024), "rollout_block" (64 | 256), "lander_offspring_per_wave" (0 = by population size | 1 | 2 | 4).
+ * "rollout_waves8" (1024), "rollout_block" (64 | 256), "lander_offspring_per_wave" (0 = by population size | 1 | 2 | 4),
+ * "box2d_lanes_per_env" (0 = by population size | 1 | 2 | 4 | 8: lanes that share one env in the LunarLander / BipedalWalker MLP rollout).
  * The library itself reads no environment variable. */
 int ses_set_tuning(ses_handle *h, const char *name, int32_t value);
 /* Timing without events: from now on the last kernel of every ses_rollout (the episode mean: end of the rollout phase)

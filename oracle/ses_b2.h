@@ -114,7 +114,7 @@ struct ContactTmp {                  // b2ContactVelocityConstraint, alive for o
 
 // World description: D provides
 //   static constexpr int NB, NJ, NSLOT (power of two), FIRST_SOLVED (bodies >= this have their contacts solved; body 0 =
-//   hull: touching the terrain ends the episode), VEL_ITERS, POS_ITERS
+//   hull: touching the terrain ends the episode), VEL_ITERS, POS_ITERS; static constexpr bool PACK_MANIFOLDS
 //   static const Poly *poly(); static const BodyDef *body(); static const JointDef *joint();
 template <class D>
 struct World {
@@ -728,36 +728,29 @@ B2_FN float contact_solve_position(const Manifold &m, Body &B, const BodyDef &bd
 
 // ------------------------------------------------------------------------------------------------------------------
 // b2World::Step(dt, D::VEL_ITERS, D::POS_ITERS)
-template <class D, class T>
-B2_FN void world_step(World<D> &w, const T &terr, float dt)
+//
+// b2Island::Solve after the velocities have been integrated: constraint setup, warm start, velocity iterations, position
+// integration, position iterations, sleep.  `mc`: the manifolds the contact rows run over, [body][row] in row order --
+// the world's own slots, or a packed copy of them (world_step below).
+template <class D>
+B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::NSLOT], float dt)
 {
-    collide(w, terr);
-
-    // b2Island::Solve: integrate velocities (gravity, no damping: v *= 1 / (1 + h * 0) is exact)
-    B2_UNROLL
-    for (int b = 0; b < D::NB; ++b) {
-        const BodyDef &bd = D::body()[b];
-        const float fx = b == 0 ? w.fx : 0.0f, fy = b == 0 ? w.fy : 0.0f;
-        w.body[b].vx += dt * (0.0f + bd.inv_mass * fx);
-        w.body[b].vy += dt * (D::GRAVITY_Y + bd.inv_mass * fy);
-    }
-    w.fx = 0.0f; w.fy = 0.0f;
-
-    ContactTmp ct[D::NB - D::FIRST_SOLVED][D::NSLOT];
+    constexpr int NBS = D::NB - D::FIRST_SOLVED;
+    ContactTmp ct[NBS][D::NSLOT];
     JointTmp jt[D::NJ];
     bool any_contact = false;
     B2_UNROLL
     for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
         B2_UNROLL
-        for (int s = 0; s < D::NSLOT; ++s) {
-            contact_init(w.mf[b - D::FIRST_SOLVED][s], ct[b - D::FIRST_SOLVED][s], w.body[b], D::body()[b], w.xf[b]);
-            any_contact = any_contact || w.mf[b - D::FIRST_SOLVED][s].count > 0;
+        for (int r = 0; r < D::NSLOT; ++r) {
+            contact_init(mc[b - D::FIRST_SOLVED][r], ct[b - D::FIRST_SOLVED][r], w.body[b], D::body()[b], w.xf[b]);
+            any_contact = any_contact || mc[b - D::FIRST_SOLVED][r].count > 0;
         }
     }
     B2_UNROLL
     for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
         B2_UNROLL
-        for (int s = 0; s < D::NSLOT; ++s) contact_warm_start(w.mf[b - D::FIRST_SOLVED][s], ct[b - D::FIRST_SOLVED][s], w.body[b], D::body()[b]);
+        for (int r = 0; r < D::NSLOT; ++r) contact_warm_start(mc[b - D::FIRST_SOLVED][r], ct[b - D::FIRST_SOLVED][r], w.body[b], D::body()[b]);
     }
     B2_UNROLL
     for (int j = 0; j < D::NJ; ++j) joint_init(w, j, jt[j], dt);
@@ -771,8 +764,8 @@ B2_FN void world_step(World<D> &w, const T &terr, float dt)
             B2_UNROLL
             for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
                 B2_UNROLL
-                for (int s = 0; s < D::NSLOT; ++s)
-                    contact_solve_velocity(w.mf[b - D::FIRST_SOLVED][s], ct[b - D::FIRST_SOLVED][s], w.body[b], D::body()[b]);
+                for (int r = 0; r < D::NSLOT; ++r)
+                    contact_solve_velocity(mc[b - D::FIRST_SOLVED][r], ct[b - D::FIRST_SOLVED][r], w.body[b], D::body()[b]);
             }
         }
     }
@@ -804,8 +797,8 @@ B2_FN void world_step(World<D> &w, const T &terr, float dt)
                 B2_UNROLL
                 for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
                     B2_UNROLL
-                    for (int s = 0; s < D::NSLOT; ++s)
-                        min_separation = b2min(min_separation, contact_solve_position(w.mf[b - D::FIRST_SOLVED][s], w.body[b], D::body()[b]));
+                    for (int r = 0; r < D::NSLOT; ++r)
+                        min_separation = b2min(min_separation, contact_solve_position(mc[b - D::FIRST_SOLVED][r], w.body[b], D::body()[b]));
                 }
             }
             const bool contacts_okay = min_separation >= -3.0f * LINEAR_SLOP;
@@ -833,6 +826,68 @@ B2_FN void world_step(World<D> &w, const T &terr, float dt)
         }
     }
     if (min_sleep >= TIME_TO_SLEEP && position_solved) w.awake = false;
+}
+
+template <class D, class T>
+B2_FN void world_step(World<D> &w, const T &terr, float dt)
+{
+    collide(w, terr);
+
+    // b2Island::Solve: integrate velocities (gravity, no damping: v *= 1 / (1 + h * 0) is exact)
+    B2_UNROLL
+    for (int b = 0; b < D::NB; ++b) {
+        const BodyDef &bd = D::body()[b];
+        const float fx = b == 0 ? w.fx : 0.0f, fy = b == 0 ? w.fy : 0.0f;
+        w.body[b].vx += dt * (0.0f + bd.inv_mass * fx);
+        w.body[b].vy += dt * (D::GRAVITY_Y + bd.inv_mass * fy);
+    }
+    w.fx = 0.0f; w.fy = 0.0f;
+
+    if constexpr (!D::PACK_MANIFOLDS) {
+        world_solve(w, w.mf, dt);
+    } else {
+        // The touching manifolds of a body, packed to the front in slot order: the solver's row order is unchanged (it
+        // skipped the empty slots anyway), so are the results.  Which slot a manifold sits in depends on where along
+        // the terrain the body stands (edge mod NSLOT); when the lanes of a wavefront carry different worlds,
+        // slot-indexed rows make the wave execute the union of everybody's slots -- packed, it executes
+        // max-over-lanes(count) rows per body.  Worth the copies for the walker (4 x 4 slots, a foot touches one or
+        // two edges: 2.5x on the rollout), not for the lander (2 x 2 slots).
+        constexpr int NBS = D::NB - D::FIRST_SOLVED;
+        Manifold mc[NBS][D::NSLOT];
+        B2_UNROLL
+        for (int b = 0; b < NBS; ++b) {
+            B2_UNROLL
+            for (int r = 0; r < D::NSLOT; ++r) mc[b][r] = Manifold{-1, 0, 0, 0.0f, 0.0f, 0.0f, 0.0f, {0.0f, 0.0f}, {0.0f, 0.0f}, {0u, 0u}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+            int n = 0;
+            B2_UNROLL
+            for (int s = 0; s < D::NSLOT; ++s) {
+                const bool touching = w.mf[b][s].count > 0;
+                B2_UNROLL
+                for (int r = 0; r <= s; ++r) {
+                    if (touching && n == r) mc[b][r] = w.mf[b][s];
+                }
+                n += touching ? 1 : 0;
+            }
+        }
+        world_solve(w, mc, dt);
+        // the accumulated impulses go back to their slots (next step's warm start, b2Contact::Update in collide())
+        B2_UNROLL
+        for (int b = 0; b < NBS; ++b) {
+            int n = 0;
+            B2_UNROLL
+            for (int s = 0; s < D::NSLOT; ++s) {
+                const bool touching = w.mf[b][s].count > 0;
+                B2_UNROLL
+                for (int r = 0; r <= s; ++r) {
+                    if (touching && n == r) {
+                        w.mf[b][s].ni[0] = mc[b][r].ni[0]; w.mf[b][s].ni[1] = mc[b][r].ni[1];
+                        w.mf[b][s].ti[0] = mc[b][r].ti[0]; w.mf[b][s].ti[1] = mc[b][r].ti[1];
+                    }
+                }
+                n += touching ? 1 : 0;
+            }
+        }
+    }
 }
 
 }  // namespace b2l

@@ -121,6 +121,7 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     h->tune_rollout_mix = 1;
     h->tune_rollout_waves8 = 1024;
     h->tune_lander_per_wave = 0;
+    h->tune_box2d_lpe = 0;
     *out = h;
     return SES_OK;
 }
@@ -139,7 +140,8 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"gru_sequential", &ses_handle::tune_gru_sequential, 0, 1},
                                  {"rollout_mix", &ses_handle::tune_rollout_mix, 0, 1},
                                  {"rollout_waves8", &ses_handle::tune_rollout_waves8, 1, 1 << 20},
-                                 {"lander_offspring_per_wave", &ses_handle::tune_lander_per_wave, 0, 4}};
+                                 {"lander_offspring_per_wave", &ses_handle::tune_lander_per_wave, 0, 4},
+                                 {"box2d_lanes_per_env", &ses_handle::tune_box2d_lpe, 0, 8}};
     for (const Knob &k : knobs) {
         if (std::strcmp(k.name, name) == 0) {
             SES_REQUIRE(value >= k.lo && value <= k.hi, "ses_set_tuning: %s = %d outside [%d, %d]", name, value, k.lo, k.hi);
@@ -147,6 +149,8 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                         "ses_set_tuning: rollout_block must be 64 or 256");
             SES_REQUIRE(k.field != &ses_handle::tune_lander_per_wave || value != 3,
                         "ses_set_tuning: lander_offspring_per_wave must be 0, 1, 2 or 4");
+            SES_REQUIRE(k.field != &ses_handle::tune_box2d_lpe || (value & (value - 1)) == 0,
+                        "ses_set_tuning: box2d_lanes_per_env must be 0, 1, 2, 4 or 8");
             h->*(k.field) = value;
             return SES_OK;
         }

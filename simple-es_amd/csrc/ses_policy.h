@@ -144,6 +144,62 @@ struct MlpSlice {
     }
 };
 
+// The same forward with the weights streamed from the offspring's (L2-resident) row instead of held in registers: for
+// kernels whose env step dwarfs the policy (the Box2D envs) and that give an env only 1 or 2 lanes, where a lane's
+// slice (32 / LPE units x (S + 1 + A) weights) would not fit the register file.  Same canonical arithmetic: the factor
+// 32 is applied to W1 / b1 on the fly (exact), groups of 4 units chain in order, balanced tree over the 8 groups.
+template <int S, int A, int LPE>
+__device__ __forceinline__ void mlp_forward_streamed(const float *__restrict__ theta, int sub, const TanhEntry *tab,
+                                                     const float (&obs)[S], float (&logits)[A])
+{
+    constexpr int U = H / LPE, G = U / 4;
+    static_assert(U % 4 == 0, "a lane owns whole fc2 groups");
+    const int j0 = sub * U;
+    const float *pw1 = theta;
+    const float *pb1 = theta + H * S;
+    const float *pw2 = pb1 + H;
+    const float *pb2 = pw2 + A * H;
+    float p[A][G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 4 * g + u;
+            float acc = SES_TANH_H_INV * pb1[j];
+#pragma unroll
+            for (int k = 0; k < S; ++k) acc = fma_(SES_TANH_H_INV * pw1[j * S + k], obs[k], acc);
+            float frac;
+            const int32_t idx = tanh_index_scaled(acc, frac);
+            a[u] = tanh_eval(tab[idx], frac, acc);
+        }
+#pragma unroll
+        for (int o = 0; o < A; ++o) {
+            const float *w = pw2 + o * H + j0 + 4 * g;
+            float acc = w[0] * a[0];
+            acc = fma_(w[1], a[1], acc);
+            acc = fma_(w[2], a[2], acc);
+            acc = fma_(w[3], a[3], acc);
+            p[o][g] = acc;
+        }
+        __builtin_amdgcn_sched_barrier(0);          // one group's loads in flight at a time: registers, not latency, are short
+    }
+#pragma unroll
+    for (int o = 0; o < A; ++o) {
+        float s;
+        if constexpr (G == 8) {
+            s = ((p[o][0] + p[o][1]) + (p[o][2] + p[o][3])) + ((p[o][4] + p[o][5]) + (p[o][6] + p[o][7]));
+        } else if constexpr (G == 4) {
+            s = (p[o][0] + p[o][1]) + (p[o][2] + p[o][3]);
+        } else if constexpr (G == 2) {
+            s = p[o][0] + p[o][1];
+        } else {
+            s = p[o][0];
+        }
+        logits[o] = lanes_sum<LPE>(s) + pb2[o];
+    }
+}
+
 // cooperative copy of the tanh table into LDS; ends with a workgroup barrier
 __device__ __forceinline__ void stage_tanh_table(TanhEntry *lds)
 {

@@ -706,9 +706,13 @@ __global__ __launch_bounds__(256, 2) void k_rollout_lander_gru(const float *__re
 }
 
 // MLP policies on the Box2D-style envs (LunarLander: conf/lunarlander.yaml, BipedalWalker: conf/bipedalwalker.yaml):
-// 8 lanes per env (4 hidden units each) for the forward, every lane of a group carries the env.  EnvB adapts an env.
+// LPE lanes per env (32 / LPE hidden units each) for the forward, every lane of a group carries the env.  The world
+// step is ~20 000 instructions whatever the number of lanes that carry an env, so LPE only decides how many waves the
+// population makes: box2d_lanes_per_env() picks the largest LPE that keeps it at about one wave per SIMD.
+// Single-wave workgroups (they spread over all SIMDs and retire independently).  EnvB adapts an env.
 struct LanderMlpEnv {
     static constexpr int S = 8, A = 4, INIT_W = 16, ROW = LL_TERRAIN_ROW;
+    static constexpr int WAVES_PER_SIMD = 2;                      // 256 registers for the kernel and for ll_step: enough
     using State = LanderState;
     __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u, float *row) { ll_reset(s, u, row); }
     __device__ static __forceinline__ void observe(const State &s, float (&obs)[S]) { ll_obs(s, obs); }
@@ -717,6 +721,10 @@ struct LanderMlpEnv {
 
 struct WalkerMlpEnv {
     static constexpr int S = 24, A = 4, INIT_W = 4, ROW = BW_TERRAIN_ROW;
+    // one wave per SIMD: bw_step (compiled for its callers' budget) may then use all 512 registers -- the walker's
+    // world does not fit 256, and what spills goes to AGPRs (one v_accvgpr move) instead of scratch memory (a trip
+    // to L2 or HBM inside the 180-iteration solver loop)
+    static constexpr int WAVES_PER_SIMD = 1;
     using State = WalkerState;
     __device__ static __forceinline__ void reset(State &s, const float *__restrict__ u, float *row) { bw_reset(s, u, row); }
     __device__ static __forceinline__ void observe(const State &s, float (&obs)[S]) { bw_obs(s, obs); }
@@ -726,25 +734,24 @@ struct WalkerMlpEnv {
     }
 };
 
-template <class EnvB>
-__global__ __launch_bounds__(256, 2) void k_rollout_box2d_mlp(const float *__restrict__ theta,
+template <class EnvB, int LPE>
+__global__ __launch_bounds__(64, EnvB::WAVES_PER_SIMD) void k_rollout_box2d_mlp(const float *__restrict__ theta,
                                                            const float *__restrict__ init, int init_per_offspring,
                                                            int n_rows, int E, int P, int max_step, uint32_t obs_mask,
                                                            double *__restrict__ ep_return,
                                                            int32_t *__restrict__ ep_steps)
 {
-    constexpr int S = EnvB::S, A = EnvB::A, LPE = 8;
+    constexpr int S = EnvB::S, A = EnvB::A;
     __shared__ TanhEntry tanh_tab[SES_TANH_N];
-    __shared__ float terrain[256 / LPE][EnvB::ROW];               // one terrain row per env
+    __shared__ float terrain[64 / LPE][EnvB::ROW];                // one terrain row per env
     stage_tanh_table(tanh_tab);
-    const long long gtid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long gtid = (long long)blockIdx.x * 64 + threadIdx.x;
     const int n_env = n_rows * E;
     int env = (int)(gtid / LPE);
     const int sub = (int)(threadIdx.x % LPE);
     const bool valid = env < n_env;
     env = valid ? env : n_env - 1;
     const int row = env / E, ep = env - row * E;
-    MlpSlice<S, A, LPE> net;
     typename EnvB::State st;
     EnvB::reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * EnvB::INIT_W, terrain[threadIdx.x / LPE]);
     double ret = 0.0;
@@ -754,12 +761,17 @@ __global__ __launch_bounds__(256, 2) void k_rollout_box2d_mlp(const float *__res
         if (__ballot(!done) == 0ull) break;
         // the lane's weight slice is re-read from the (L2-resident) row every step: a few dozen loads next to a
         // 20 000-instruction world step, and nothing of the policy has to stay in registers across it
-        net.load(theta + (size_t)row * P, sub);
         float obs[S], logits[A], act[A];
         EnvB::observe(st, obs);
 #pragma unroll
         for (int k = 0; k < S; ++k) obs[k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
-        net.forward(tanh_tab, obs, logits);
+        if constexpr (LPE >= 4) {
+            MlpSlice<S, A, LPE> net;
+            net.load(theta + (size_t)row * P, sub);
+            net.forward(tanh_tab, obs, logits);
+        } else {
+            mlp_forward_streamed<S, A, LPE>(theta + (size_t)row * P, sub, tanh_tab, obs, logits);
+        }
 #pragma unroll
         for (int k = 0; k < A; ++k) act[k] = tanh_(tanh_tab, logits[k]);
         if (!done) {                                               // a finished env is frozen
@@ -1007,6 +1019,32 @@ static void launch_rollout(const ses_handle *h, const float *theta, const float 
 // eval_ep_num from which the GRU rollouts run on the matrix cores (ses_set_tuning "gru_mfma_min_e", default 12).
 // Measured, POMDP CartPole, 4096 offspring x 500 steps: the MFMA form takes 5.1 ms for any E <= 16 (the padded tile
 // costs the same), the VALU lockstep form 2.4 / 3.5 / 5.6 / 7.2 ms at E = 5 / 8 / 12 / 16 -- the crossover is at 12.
+// lanes per env of the Box2D MLP rollout: as many as keep the population within ~one wave per SIMD (1024 SIMDs)
+static int box2d_lanes_per_env(const ses_handle *h, long long episodes)
+{
+    if (h->tune_box2d_lpe) return h->tune_box2d_lpe;
+    int lpe = 8;
+    while (lpe > 1 && episodes * lpe > 64ll * 1024) lpe >>= 1;
+    return lpe;
+}
+
+template <class EnvB>
+static void launch_box2d_mlp(ses_handle *h, const float *theta, const float *init, int per, int n_rows, double *epr,
+                             int32_t *ep_steps)
+{
+    const long long episodes = (long long)n_rows * h->cfg.eval_ep_num;
+    const int lpe = box2d_lanes_per_env(h, episodes);
+    const dim3 grid(ceil_div(episodes * lpe, 64)), block(64);
+#define SES_BOX2D_LAUNCH(L)                                                                                          \
+    hipLaunchKernelGGL((k_rollout_box2d_mlp<EnvB, L>), grid, block, 0, h->stream, theta, init, per, n_rows,           \
+                       h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, epr, ep_steps)
+    if (lpe == 8) SES_BOX2D_LAUNCH(8);
+    else if (lpe == 4) SES_BOX2D_LAUNCH(4);
+    else if (lpe == 2) SES_BOX2D_LAUNCH(2);
+    else SES_BOX2D_LAUNCH(1);
+#undef SES_BOX2D_LAUNCH
+}
+
 static int gru_mfma_min_e(const ses_handle *h) { return h->tune_gru_mfma_min_e; }
 
 // Small populations: the chip is far from full and what a rollout costs is the latency of max_step sequential env
@@ -1113,15 +1151,11 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
                                init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, epr,
                                ep_steps, 0);
         else
-            hipLaunchKernelGGL((k_rollout_box2d_mlp<LanderMlpEnv>), dim3(ceil_div((long long)episodes * 8, 256)), dim3(256), 0,
-                               h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
-                               h->cfg.max_step, h->obs_mask, epr, ep_steps);
+            launch_box2d_mlp<LanderMlpEnv>(h, theta, init, init_per_offspring, n_rows, epr, ep_steps);
     } else if (h->cfg.env_id == SES_ENV_BIPEDALWALKER) {
         SES_REQUIRE(mode == SES_MODE_EPISODIC, "ses_rollout: BipedalWalker has no fixed-length mode");
         SES_REQUIRE(!h->cfg.gru, "ses_rollout: BipedalWalker has an MLP-policy kernel only (conf/bipedalwalker.yaml: gru False)");
-        hipLaunchKernelGGL((k_rollout_box2d_mlp<WalkerMlpEnv>), dim3(ceil_div((long long)episodes * 8, 256)), dim3(256), 0,
-                           h->stream, theta, init, init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P,
-                           h->cfg.max_step, h->obs_mask, epr, ep_steps);
+        launch_box2d_mlp<WalkerMlpEnv>(h, theta, init, init_per_offspring, n_rows, epr, ep_steps);
     } else if (h->cfg.env_id == SES_ENV_SIMPLE_SPREAD) {
         SES_REQUIRE(ep_steps == nullptr, "ses_rollout: simple_spread episodes have a fixed length, no ep_steps");
         const int blocks = ceil_div((long long)episodes * 8, 64);

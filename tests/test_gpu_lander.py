@@ -35,12 +35,15 @@ def test_lander_gru_golden_and_oracle(golden_dir):
     es.close()
 
 
-@pytest.mark.parametrize("gru,pomdp", [(True, False), (False, True), (False, False)])
-def test_lander_population_bit_exact(gru, pomdp):
+@pytest.mark.parametrize("gru,pomdp,lpe", [(True, False, 0), (False, True, 0), (False, False, 0), (False, False, 4),
+                                           (False, True, 2), (False, False, 1)])
+def test_lander_population_bit_exact(gru, pomdp, lpe):
+    """lpe: lanes per env of the MLP rollout kernel (0 = the library's choice, 8 at this size)."""
     from ses import HipES
     rng = np.random.RandomState(int(gru) * 2 + int(pomdp))
     n = 70
     es = HipES("LunarLanderContinuous-v2", 8, 4, False, gru, pomdp=pomdp, max_step=250, eval_ep_num=4)
+    es.set_tuning("box2d_lanes_per_env", lpe)
     theta = (rng.randn(n, es.P) * rng.choice([0.05, 0.3, 1.0], size=(n, 1))).astype(np.float32)
     init = es.init_states_uniform(11, 2, 50, n)                         # [n, 4, 16] uniforms in [0,1)
     want_init = co.init_states_uniform(11, 2, 50, n, 4, 16, False, 0.0, 1.0)

@@ -20,11 +20,13 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("n,E,T", [(1, 1, 40), (37, 3, 150)])
-def test_walker_population_bit_exact(n, E, T):
+@pytest.mark.parametrize("n,E,T,lpe", [(1, 1, 40, 0), (37, 3, 150, 0), (37, 3, 150, 4), (37, 3, 150, 2), (37, 3, 150, 1)])
+def test_walker_population_bit_exact(n, E, T, lpe):
+    """lpe: lanes per env of the rollout kernel (0 = the library's choice, 8 at this size); 1 and 2 stream the weights."""
     from ses import HipES
     rng = np.random.RandomState(n)
     es = HipES("BipedalWalker-v3", 24, 4, False, False, max_step=T, eval_ep_num=E)
+    es.set_tuning("box2d_lanes_per_env", lpe)
     assert es.P == 932
     theta = (rng.randn(n, es.P) * rng.choice([0.1, 0.5, 2.0], size=(n, 1))).astype(np.float32)
     init = es.init_states_uniform(3, 1, 20, n)                          # [n, E, 4] uniforms in [0,1)
