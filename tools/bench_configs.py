@@ -85,6 +85,10 @@ def main():
     rollout_case("LunarLanderContinuous-v2 MLP (conf/lunarlander.yaml)", es, n, 2.0, MODE_EPISODIC, reps)
     es.close()
 
+    es = HipES("BipedalWalker-v3", 24, 4, False, False, max_step=300, eval_ep_num=5)
+    rollout_case("BipedalWalker-v3 MLP (conf/bipedalwalker.yaml)", es, n, 2.0, MODE_EPISODIC, min(reps, 3))
+    es.close()
+
     for agents, S in ((3, 18), (2, 12)):
         es = HipES("simple_spread", S, 5, True, False, max_step=25, eval_ep_num=5, n_agents=agents)
         rollout_case(f"C5 simple_spread, {agents} agents (world steps; {agents} forwards each)", es, n, 1.0, MODE_EPISODIC,

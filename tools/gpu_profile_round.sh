@@ -11,3 +11,4 @@ mkdir -p gpurun_out/sq_mlp && rm -rf gpurun_out/sq_mlp/* && mv gpurun_out/sq_1 g
 bash tools/prof_sq.sh --no-extras --gru > gpurun_out/sq_gru.txt 2>&1; tail -3 gpurun_out/sq_gru.txt
 mkdir -p gpurun_out/sq_gru && rm -rf gpurun_out/sq_gru/* && mv gpurun_out/sq_1 gpurun_out/sq_2 gpurun_out/sq_gru/
 bash tools/prof_sq_c3.sh 4096 > gpurun_out/sq_c3.txt 2>&1; tail -3 gpurun_out/sq_c3.txt
+python tools/bench_configs.py > gpurun_out/configs.jsonl 2> gpurun_out/configs.err; tail -2 gpurun_out/configs.jsonl | cut -c1-200

@@ -8,3 +8,5 @@ python bench.py "$@" > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "benc
 for cfg in cartpole_openai.yaml cartpole.yaml cartpole_pomdp_gru.yaml simplespread.yaml lunarlander_openai.yaml; do
   python tools/time_loop.py $cfg 2>&1 | tail -1
 done | tee gpurun_out/time_loop.txt
+python tools/time_loop.py lunarlander.yaml 0 300 2>&1 | tail -1 | tee -a gpurun_out/time_loop.txt
+python tools/time_loop.py bipedalwalker.yaml 0 60 2>&1 | tail -1 | tee -a gpurun_out/time_loop.txt
