@@ -121,6 +121,38 @@ def test_policy_forward_bit_exact(S, A, disc):
     h.close()
 
 
+def test_tanh_special_arguments_on_the_hardware():
+    """The table tanh at the arguments where an instruction's corner case could separate the device from the CPU build:
+    interval boundaries and their neighbours (v_fract_f32 / v_cvt_i32_f32 of the same value must agree), zeros,
+    denormals, the clamp at 10, infinities and NaN (v_min_f32 absorbs it).  Probed through a network that routes one
+    input straight into one hidden unit and that unit straight into logit 0: logits[0] == tanh(x), act[0] ==
+    tanh(tanh(x)); also exactly odd, which the reference's exact argmax ties rely on."""
+    from ses import HipES
+    S, A = 4, 2
+    h = HipES(None, S, A, False, False)
+    grid = np.arange(-10.5, 10.5, 1 / 32, dtype=np.float32)
+    xs = np.concatenate([grid, np.nextafter(grid, np.float32(-20)), np.nextafter(grid, np.float32(20)),
+                         np.float32([0.0, -0.0, -1e-45, 1e-45, -1e-38, -1e-30, -1e-10, -3e-9, -2e-8, 1e-10, 9.9999990463, -9.9999990463,
+                                     10.0, -10.0, 50.0, -50.0, 1e30, -1e30, np.inf, -np.inf, np.nan]),
+                         np.random.RandomState(0).randn(4000).astype(np.float32) * 3]).astype(np.float32)
+    n = xs.shape[0]
+    theta = np.zeros((n, h.P), np.float32)
+    theta[:, 5 * S + 0] = 1.0                           # W1[5][0] = 1: hidden unit 5 sees obs[0]
+    theta[:, 32 * S + 32 + 5] = 1.0                     # W2[0][5] = 1: logit 0 sees hidden unit 5
+    obs = np.zeros((n, S), np.float32)
+    obs[:, 0] = xs
+    _, logits, act = h.policy_forward(dev(theta), dev(obs))
+    _, o_logits, o_act, _ = co.policy_forward(S, A, False, False, theta, obs)
+    assert_bit_equal(host(logits), o_logits, "tanh(x)")
+    assert_bit_equal(host(act), o_act, "tanh(tanh(x))")
+    finite = np.isfinite(xs)
+    assert np.abs(o_logits[finite, 0] - np.tanh(xs[finite].astype(np.float64))).max() <= 1.2e-7
+    obs[:, 0] = -xs
+    _, neg_logits, _ = h.policy_forward(dev(theta), dev(obs))
+    assert np.array_equal(host(neg_logits)[finite, 0], -o_logits[finite, 0])   # as values: the logit's sum of zeros turns -0 into +0
+    h.close()
+
+
 def test_policy_forward_golden_g1(golden_dir):
     """Device forward against the REFERENCE's own outputs (fixture G1), fp32 tolerance."""
     from ses import HipES
