@@ -321,10 +321,12 @@ def run_rank(args):
     job.generations(args.warmup)
     times = timed_blocks(job, args.steps, max(args.blocks, 1), barrier, dist, world)
     weak = summarise(job, args.steps, times)
-    from ses.parallel import comm_info
+    from ses.parallel import comm_info, comm_transport
     comm_rank, comm_world, rccl_version = comm_info(job.loop.dev)
+    transport = comm_transport(job.loop.dev, -(-job.n_global // world)) if world > 1 else "none"
     weak.update(job.phases())
     weak["rccl_ranks"] = comm_world
+    weak["allgather_transport"] = transport
 
     result = {
         "metric": METRIC, "value": weak["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -337,9 +339,11 @@ def run_rank(args):
                    "offspring_per_gpu": args.offspring_per_gpu, "offspring_total": job.n_global, "eval_ep_num": E,
                    "max_step": T, "env_steps_per_generation": job.steps_per_generation(),
                    "noise": "rocRAND philox4x32_10", "preroll_generations": preroll,
-                   "parallelism": f"population sharded over {world} GPU(s), fitness all-gather "
-                                  f"(ses_allgather_fitness, RCCL {rccl_version}, {comm_world} rank(s))" if comm_world else
-                                  f"population on {world} GPU(s)" + ("" if world == 1 else f", fitness all-gather via torch.distributed/{backend}")},
+                   "parallelism": (f"population on {world} GPU(s)" if world == 1 else
+                                   f"population sharded over {world} GPU(s), fitness all-gather by ses_allgather_fitness: " +
+                                   {"p2p-store": "peer stores into IPC-mapped mailboxes over xGMI (one kernel per rank)",
+                                    "rccl": f"ncclAllGather, RCCL {rccl_version}, {comm_world} rank(s)",
+                                    "torch": f"FALLBACK torch.distributed/{backend} (no library transport could be set up)"}[transport])},
         "parity": PARITY_NOTE,
         "weak_4096_per_gpu": weak,
     }
@@ -361,6 +365,7 @@ def run_rank(args):
                 rec = summarise(j, x_steps, t)
                 rec.update(j.phases())
                 rec["rccl_ranks"] = comm_info(j.loop.dev)[1]
+                rec["allgather_transport"] = comm_transport(j.loop.dev, -(-n_total // world)) if world > 1 else "none"
                 result[key] = rec
                 del j
             except Exception as exc:                                 # the headline line must still be printed

@@ -249,6 +249,24 @@ int ses_comm_init(ses_handle *h, int32_t rank, int32_t world, const void *id);
 int ses_comm_info(ses_handle *h, int32_t *rank, int32_t *world, int32_t *rccl_version);
 int ses_comm_destroy(ses_handle *h); /* also done by ses_destroy */
 int ses_allgather_fitness(ses_handle *h, const float *local, int32_t n_per_rank, float *all);
+/*
+ * The same exchange by PEER STORES inside one node (no RCCL, no ring): every rank owns a mailbox in fine-grained device
+ * memory, the W - 1 peers map it (hipIpc*), and one small kernel per rank stores its shard into every peer's mailbox,
+ * publishes a sequence number and collects the peers' shards from its own mailbox -- the latency of one xGMI store
+ * instead of W - 1 ring hops behind a library launch.  Once attached, ses_allgather_fitness uses it for n_per_rank <=
+ * max_per_rank (results identical: it is a copy).  A wait that exceeds 2 s NaN-fills the missing shard and makes the
+ * next ses_allgather_fitness fail with SES_ERR_COMM; after ses_comm_p2p_detach the handle is back on RCCL.
+ *   ses_comm_p2p_export : allocate this rank's mailbox; handle[SES_COMM_P2P_HANDLE_BYTES] is what the peers need.
+ *   ses_comm_p2p_attach : handles = the W exported handles in rank order (W * SES_COMM_P2P_HANDLE_BYTES bytes, gathered
+ *                         by the host's control plane); maps the peers.  Every rank must have exported before any attaches.
+ *   ses_comm_p2p_info   : world (0 = not attached), max_per_rank, exchanges done so far; any pointer may be NULL.
+ * Ranks may share a GPU (several processes on one device): that is how the single-GPU tests drive this path.
+ */
+#define SES_COMM_P2P_HANDLE_BYTES 64
+int ses_comm_p2p_export(ses_handle *h, int32_t rank, int32_t world, int32_t max_per_rank, void *handle);
+int ses_comm_p2p_attach(ses_handle *h, const void *handles);
+int ses_comm_p2p_info(ses_handle *h, int32_t *world, int32_t *max_per_rank, int32_t *exchanges);
+int ses_comm_p2p_detach(ses_handle *h);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,19 @@
 // inside a process that has torch loaded the already-mapped library is reused, so there is never a second RCCL in
 // the address space).  A single-GPU user never loads it.  Only the six entry points below are used; their C
 // signatures are part of NCCL's stable API (ncclUniqueId = 128 opaque bytes passed by value, ncclFloat32 = 7).
+//
+// Second transport, inside one node: PEER STORES.  The exchange is 16-256 KB in total and happens once per ~0.25 ms
+// generation, so what it costs is latency, not bandwidth: a ring all-gather is W - 1 dependent hops behind a library
+// launch.  xGMI is point-to-point and every GPU can store into every other GPU's memory, so each rank owns a MAILBOX
+// (fine-grained device memory, exported with hipIpcGetMemHandle and mapped by the W - 1 peers) and ONE small kernel
+// per rank does the whole exchange: workgroup b stores the local shard into peer b's mailbox, publishes a sequence
+// number there (system-scope release), waits for peer b's sequence number in its own mailbox (acquire) and copies
+// peer b's shard out -- one store, one flag, no hops, no intermediate rank.  Two slots alternate by sequence parity:
+// a peer can only be one exchange ahead (its next exchange needs this rank's next flag, which is stream-ordered after
+// this rank's reads), so slot (seq & 1) is never overwritten while it is still being read.
+// A wait gives up after P2P_TIMEOUT_TICKS of the 100 MHz real-time counter: the shard is filled with NaN and a
+// host-visible error word is set, which the next ses_allgather_fitness reports (SES_ERR_COMM) -- no kernel of this
+// library spins for ever.
 #include <dlfcn.h>
 
 #include <cstring>
@@ -31,6 +44,90 @@ struct Rccl {
 };
 
 static Rccl g_rccl;
+
+// ---- peer-store transport ---------------------------------------------------------------------------------------
+constexpr int P2P_MAX_WORLD = 16;
+constexpr unsigned long long P2P_TIMEOUT_TICKS = 200000000ull;   // 2 s of the 100 MHz counter
+
+}  // namespace ses
+
+struct ses_p2p {
+    int rank, world, max_per_rank, splits_max;
+    bool attached;
+    size_t bytes, flag_offset;              // mailbox layout: float data[2][world][max_per_rank] | uint32 flags[2][world][splits_max]
+    void *own;                              // this rank's mailbox (device memory, fine-grained)
+    void *peer[ses::P2P_MAX_WORLD];         // peer[r]: rank r's mailbox as mapped here (peer[rank] == own)
+    uint32_t seq;                           // exchanges issued so far
+    uint32_t *err_host;                     // pinned host word set by a kernel that timed out
+    uint32_t *err_dev;                      // its device alias
+};
+
+namespace ses {
+
+struct P2pPeers {
+    float *data[P2P_MAX_WORLD];
+    uint32_t *flags[P2P_MAX_WORLD];
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int P2P_SPLIT = 4096;          // floats one workgroup moves; a shard of n floats takes ceil(n / P2P_SPLIT) workgroups per peer
+
+// workgroup (b, s): slice s of the local shard -> peer b's mailbox, then slice s of peer b's shard (from this rank's
+// mailbox) -> out.  Every (source rank, slice) has its own sequence word, so no workgroup waits for another one of
+// its own grid.  16-byte accesses when n and the pointers allow (the mailbox is uncached memory: wide and few).
+__global__ __launch_bounds__(256) void k_allgather_p2p(const float *__restrict__ local, int n, int max_per_rank, int splits_max,
+                                                       int rank, int world, uint32_t seq, P2pPeers peers,
+                                                       float *__restrict__ out, uint32_t *err, int vec4)
+{
+    const int b = blockIdx.x, sp = blockIdx.y, slot = (int)(seq & 1u);
+    const int i0 = sp * P2P_SPLIT, i1 = i0 + P2P_SPLIT < n ? i0 + P2P_SPLIT : n;
+    float *dst = peers.data[b] + ((size_t)slot * world + rank) * max_per_rank;
+    if (vec4) {
+        for (int i = i0 + 4 * threadIdx.x; i < i1; i += 1024)
+            __builtin_nontemporal_store(*reinterpret_cast<const f32x4 *>(local + i), reinterpret_cast<f32x4 *>(dst + i));
+    } else {
+        for (int i = i0 + threadIdx.x; i < i1; i += 256) __builtin_nontemporal_store(local[i], dst + i);
+    }
+    __threadfence_system();                                           // the slice is visible to peer b ...
+    __syncthreads();
+    if (threadIdx.x == 0)                                              // ... before its sequence number is
+        __hip_atomic_store(peers.flags[b] + ((size_t)slot * world + rank) * splits_max + sp, seq, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        const uint32_t *flag = peers.flags[rank] + ((size_t)slot * world + b) * splits_max + sp;
+        const unsigned long long t0 = real_time();
+        int good = 1;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            if (real_time() - t0 > P2P_TIMEOUT_TICKS) { good = 0; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        ok = good;
+        if (!good) atomicOr_system(err, 1u << (b & 31));
+    }
+    __syncthreads();
+    const float *src = peers.data[rank] + ((size_t)slot * world + b) * max_per_rank;
+    float *o = out + (size_t)b * n;
+    if (vec4) {
+        const float nan = __builtin_nanf("");
+        for (int i = i0 + 4 * threadIdx.x; i < i1; i += 1024) {
+            const f32x4 v = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + i)) : f32x4{nan, nan, nan, nan};
+            *reinterpret_cast<f32x4 *>(o + i) = v;
+        }
+    } else {
+        for (int i = i0 + threadIdx.x; i < i1; i += 256) o[i] = ok ? __builtin_nontemporal_load(src + i) : __builtin_nanf("");
+    }
+}
+
+static void p2p_free(ses_p2p *p)
+{
+    if (!p) return;
+    for (int r = 0; r < p->world && p->attached; ++r)
+        if (r != p->rank && p->peer[r]) (void)hipIpcCloseMemHandle(p->peer[r]);
+    if (p->own) (void)hipFree(p->own);
+    if (p->err_host) (void)hipHostFree(p->err_host);
+    delete p;
+}
 
 static int rccl_error(const char *what, int rc)
 {
@@ -72,6 +169,11 @@ int comm_release(ses_handle *h)
     h->comm = nullptr;
     h->comm_world = 0;
     h->comm_rank = 0;
+    if (h->p2p) {
+        (void)hipStreamSynchronize(h->stream);
+        p2p_free(h->p2p);
+        h->p2p = nullptr;
+    }
     return SES_OK;
 }
 
@@ -132,12 +234,115 @@ int ses_comm_destroy(ses_handle *h)
     return ses::comm_release(h);
 }
 
+int ses_comm_p2p_export(ses_handle *h, int32_t rank, int32_t world, int32_t max_per_rank, void *handle)
+{
+    using namespace ses;
+    SES_REQUIRE(h && handle, "ses_comm_p2p_export: null argument");
+    SES_REQUIRE(world >= 2 && world <= P2P_MAX_WORLD && rank >= 0 && rank < world,
+                "ses_comm_p2p_export: rank %d / world %d (2 <= world <= %d)", rank, world, P2P_MAX_WORLD);
+    SES_REQUIRE(max_per_rank >= 1, "ses_comm_p2p_export: max_per_rank must be >= 1");
+    SES_REQUIRE(!h->p2p, "ses_comm_p2p_export: this handle already has a mailbox");
+    static_assert(sizeof(hipIpcMemHandle_t) <= SES_COMM_P2P_HANDLE_BYTES, "handle size");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    ses_p2p *p = new ses_p2p();
+    std::memset(p, 0, sizeof *p);
+    p->rank = rank; p->world = world;
+    p->max_per_rank = (max_per_rank + 3) / 4 * 4;                     // slots stay 16-byte aligned
+    p->splits_max = ceil_div(p->max_per_rank, P2P_SPLIT);
+    p->flag_offset = (sizeof(float) * 2 * (size_t)world * p->max_per_rank + 255) / 256 * 256;
+    p->bytes = p->flag_offset + sizeof(uint32_t) * 2 * (size_t)world * p->splits_max;
+    hipError_t e = hipExtMallocWithFlags(&p->own, p->bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p->own, p->bytes, hipDeviceMallocFinegrained); }
+    if (e != hipSuccess) {
+        p->own = nullptr; p2p_free(p);
+        return set_error(SES_ERR_COMM, "ses_comm_p2p_export: no fine-grained device memory for the mailbox: %s", hipGetErrorString(e));
+    }
+    e = hipMemset(p->own, 0, p->bytes);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&p->err_host, sizeof(uint32_t), hipHostMallocMapped);
+    if (e == hipSuccess) { *p->err_host = 0u; e = hipHostGetDevicePointer((void **)&p->err_dev, p->err_host, 0); }
+    hipIpcMemHandle_t ipc;
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&ipc, p->own);
+    if (e != hipSuccess) {
+        p2p_free(p);
+        return set_error(SES_ERR_COMM, "ses_comm_p2p_export failed: %s", hipGetErrorString(e));
+    }
+    std::memset(handle, 0, SES_COMM_P2P_HANDLE_BYTES);
+    std::memcpy(handle, &ipc, sizeof ipc);
+    p->peer[rank] = p->own;
+    h->p2p = p;
+    return SES_OK;
+}
+
+int ses_comm_p2p_attach(ses_handle *h, const void *handles)
+{
+    using namespace ses;
+    SES_REQUIRE(h && handles, "ses_comm_p2p_attach: null argument");
+    SES_REQUIRE(h->p2p && !h->p2p->attached, "ses_comm_p2p_attach: export a mailbox first (once)");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    ses_p2p *p = h->p2p;
+    for (int r = 0; r < p->world; ++r) {
+        if (r == p->rank) continue;
+        hipIpcMemHandle_t ipc;
+        std::memcpy(&ipc, (const char *)handles + (size_t)r * SES_COMM_P2P_HANDLE_BYTES, sizeof ipc);
+        const hipError_t e = hipIpcOpenMemHandle(&p->peer[r], ipc, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            for (int q = 0; q < r; ++q)
+                if (q != p->rank && p->peer[q]) { (void)hipIpcCloseMemHandle(p->peer[q]); p->peer[q] = nullptr; }
+            p->peer[r] = nullptr;
+            return set_error(SES_ERR_COMM, "ses_comm_p2p_attach: cannot map the mailbox of rank %d: %s", r, hipGetErrorString(e));
+        }
+    }
+    p->attached = true;
+    return SES_OK;
+}
+
+int ses_comm_p2p_info(ses_handle *h, int32_t *world, int32_t *max_per_rank, int32_t *exchanges)
+{
+    SES_REQUIRE(h, "ses_comm_p2p_info: null handle");
+    const bool on = h->p2p && h->p2p->attached;
+    if (world) *world = on ? h->p2p->world : 0;                     // 0: the transport is not attached
+    if (max_per_rank) *max_per_rank = on ? h->p2p->max_per_rank : 0;
+    if (exchanges) *exchanges = on ? (int32_t)h->p2p->seq : 0;
+    return SES_OK;
+}
+
+int ses_comm_p2p_detach(ses_handle *h)
+{
+    SES_REQUIRE(h, "ses_comm_p2p_detach: null handle");
+    if (h->p2p) {
+        (void)hipStreamSynchronize(h->stream);
+        ses::p2p_free(h->p2p);
+        h->p2p = nullptr;
+    }
+    return SES_OK;
+}
+
 int ses_allgather_fitness(ses_handle *h, const float *local, int32_t n_per_rank, float *all)
 {
     using namespace ses;
     SES_REQUIRE(h && local && all, "ses_allgather_fitness: null argument");
     SES_REQUIRE(n_per_rank >= 1, "ses_allgather_fitness: n_per_rank must be >= 1");
-    SES_REQUIRE(h->comm, "ses_allgather_fitness: no communicator (call ses_comm_init first)");
+    if (h->p2p && h->p2p->attached && n_per_rank <= h->p2p->max_per_rank) {
+        ses_p2p *p = h->p2p;
+        if (*(volatile uint32_t *)p->err_host != 0u)
+            return set_error(SES_ERR_COMM, "ses_allgather_fitness: an earlier peer-store exchange timed out waiting for rank mask 0x%x "
+                             "(its output was NaN-filled); detach the transport (ses_comm_p2p_detach) to continue over RCCL",
+                             *(volatile uint32_t *)p->err_host);
+        SES_HIP_TRY(hipSetDevice(h->cfg.device));
+        P2pPeers peers;
+        std::memset(&peers, 0, sizeof peers);
+        for (int r = 0; r < p->world; ++r) {
+            peers.data[r] = (float *)p->peer[r];
+            peers.flags[r] = (uint32_t *)((char *)p->peer[r] + p->flag_offset);
+        }
+        p->seq += 1;
+        const int vec4 = (n_per_rank % 4 == 0) && ((uintptr_t)local % 16 == 0) && ((uintptr_t)all % 16 == 0);
+        hipLaunchKernelGGL(k_allgather_p2p, dim3(p->world, ceil_div(n_per_rank, P2P_SPLIT)), dim3(256), 0, h->stream, local,
+                           (int)n_per_rank, p->max_per_rank, p->splits_max, p->rank, p->world, p->seq, peers, all, p->err_dev, vec4);
+        SES_HIP_TRY(hipGetLastError());
+        return SES_OK;
+    }
+    SES_REQUIRE(h->comm, "ses_allgather_fitness: no communicator (call ses_comm_init or ses_comm_p2p_attach first)");
     SES_HIP_TRY(hipSetDevice(h->cfg.device));
     int nrc = g_rccl.AllGather(local, all, (size_t)n_per_rank, NCCL_FLOAT32, (NcclComm)h->comm, h->stream);
     if (nrc != 0) return rccl_error("ncclAllGather", nrc);

@@ -21,6 +21,8 @@ struct ses_handle {
     // multi-GPU (ses_comm.hip): RCCL communicator of this rank, null until ses_comm_init
     void *comm;
     int comm_rank, comm_world;
+    // peer-store transport of the same exchange (ses_comm_p2p_*): this rank's mailbox and the peers' mapped ones
+    struct ses_p2p *p2p;
     // kernel-selection thresholds (ses_set_tuning; the defaults are the measured crossovers, ses_rollout.hip)
     int tune_rollout_block;        // workgroup size of the pure-LPE CartPole MLP rollout: 64 or 256
     int tune_gru_mfma_min_e;       // eval_ep_num from which GRU rollouts run on the MFMA kernel

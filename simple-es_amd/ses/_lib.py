@@ -76,8 +76,13 @@ SIGNATURES = {
     "ses_comm_info": [_vp, _vp, _vp, _vp],
     "ses_comm_destroy": [_vp],
     "ses_allgather_fitness": [_vp, _vp, _i32, _vp],
+    "ses_comm_p2p_export": [_vp, _i32, _i32, _i32, _vp],
+    "ses_comm_p2p_attach": [_vp, _vp],
+    "ses_comm_p2p_info": [_vp, _vp, _vp, _vp],
+    "ses_comm_p2p_detach": [_vp],
 }
 COMM_ID_BYTES = 128
+COMM_P2P_HANDLE_BYTES = 64
 _RESTYPE = {"ses_last_error": ctypes.c_char_p, "ses_version": ctypes.c_char_p}
 
 _lib = None

@@ -196,11 +196,34 @@ class HipES:
     def comm_destroy(self):
         check(self._lib.ses_comm_destroy(self._h), "ses_comm_destroy")
 
+    def comm_p2p_export(self, rank, world, max_per_rank):
+        """ses_comm_p2p_export: allocate this rank's mailbox of the peer-store transport; returns the 64 handle bytes the
+        peers need (gather them over the control plane and pass all of them, in rank order, to comm_p2p_attach)."""
+        buf = ctypes.create_string_buffer(_lib.COMM_P2P_HANDLE_BYTES)
+        check(self._lib.ses_comm_p2p_export(self._h, int(rank), int(world), int(max_per_rank), buf), "ses_comm_p2p_export")
+        return buf.raw
+
+    def comm_p2p_attach(self, handles):
+        blob = b"".join(bytes(h) for h in handles)
+        check(self._lib.ses_comm_p2p_attach(self._h, ctypes.create_string_buffer(blob, len(blob))), "ses_comm_p2p_attach")
+
+    def comm_p2p_info(self):
+        """(world, max_per_rank, exchanges); world == 0 means the peer-store transport is not attached."""
+        w, m, x = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        check(self._lib.ses_comm_p2p_info(self._h, ctypes.byref(w), ctypes.byref(m), ctypes.byref(x)), "ses_comm_p2p_info")
+        return w.value, m.value, x.value
+
+    def comm_p2p_detach(self):
+        check(self._lib.ses_comm_p2p_detach(self._h), "ses_comm_p2p_detach")
+
     def allgather_fitness(self, local, out=None):
-        """local float32[n_per_rank] on every rank -> float32[world * n_per_rank], rank-major, identical everywhere."""
-        _, world, _ = self.comm_info()
+        """local float32[n_per_rank] on every rank -> float32[world * n_per_rank], rank-major, identical everywhere.
+        Peer stores when that transport is attached and the shard fits its mailbox, RCCL otherwise."""
+        world, cap, _ = self.comm_p2p_info()
+        if world < 1 or local.shape[0] > cap:
+            _, world, _ = self.comm_info()
         if world < 1:
-            raise SesError("allgather_fitness: the handle has no communicator (comm_init first)")
+            raise SesError("allgather_fitness: the handle has no communicator (comm_init or comm_p2p_attach first)")
         n = local.shape[0]
         self._chk(local, "local", torch.float32, (n,))
         out = self.empty(world * n) if out is None else self._chk(out, "all", torch.float32, (world * n,))

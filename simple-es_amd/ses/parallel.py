@@ -7,10 +7,10 @@ all-gather of the per-offspring fitness (N * 4 bytes: latency-bound over xGMI, n
 Noise is counter-based on the GLOBAL row index, so every rank can regenerate any row and computes the
 identical parent update without a second collective.
 
-The collective itself lives in the C library (`ses_allgather_fitness`, RCCL on the handle's stream):
-`attach_comm(dev)` creates the handle's communicator, using torch.distributed only as the control plane that
-carries rank 0's 128-byte unique id to the other ranks.  The torch.distributed route further down is the test
-rig: backend "gloo" with several ranks sharing one GPU (RCCL refuses duplicate devices) or CPU tensors.
+The collective itself lives in the C library (`ses_allgather_fitness` on the handle's stream: peer stores into mapped
+mailboxes inside a node, RCCL otherwise): `attach_comm(dev)` sets the transports up, using torch.distributed only as the
+control plane that carries the mailbox handles / rank 0's 128-byte RCCL id between the ranks.  The torch.distributed
+route further down is what is left when neither is available (CPU tensors, or SES_COMM_P2P=0 with backend "gloo").
 """
 import torch
 import torch.distributed as dist
@@ -20,49 +20,110 @@ def _dist_on():
     return dist.is_available() and dist.is_initialized()
 
 
-_COMM = {}   # (group, world) -> HipES handle that owns this process's RCCL communicator, or False (torch route)
+_COMM = {}   # (group, world) -> HipES handle that owns this process's communicator(s), or False (torch route)
+P2P_MAX_PER_RANK = 65536          # floats per rank a mailbox slot holds (256 KB): every population this repo shards fits
+
+
+def _cpu_group_ok(ok, device, group):
+    """MIN over the ranks of a 0/1 flag (one rank failed -> nobody uses the transport)."""
+    backend = dist.get_backend(group)
+    flag = torch.tensor([int(ok)], dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag.item()) == 1
+
+
+def _attach_p2p(owner, rank, world, group):
+    """Peer-store transport (ses_comm_p2p_*): every rank exports a mailbox, the handles travel over the control plane,
+    every rank maps the others; then ONE exchange of a known pattern is checked on every rank.  All ranks must be on one
+    node.  Any failure on any rank -> every rank detaches (collective decision)."""
+    import os, socket
+    if os.environ.get("SES_COMM_P2P", "1") == "0" or not 2 <= world <= 16:
+        return False
+    hosts = [None] * world
+    dist.all_gather_object(hosts, socket.gethostname(), group=group)
+    ok, handle = len(set(hosts)) == 1, None
+    if ok:
+        try:
+            handle = owner.comm_p2p_export(rank, world, P2P_MAX_PER_RANK)
+        except Exception as exc:
+            ok = False
+            print(f"[ses] rank {rank}: peer-store mailbox not available ({exc})", file=__import__("sys").stderr, flush=True)
+    handles = [None] * world
+    dist.all_gather_object(handles, handle, group=group)
+    ok = ok and all(h is not None for h in handles)
+    if ok:
+        try:
+            owner.comm_p2p_attach(handles)
+        except Exception as exc:
+            ok = False
+            print(f"[ses] rank {rank}: peer mailboxes not mappable ({exc})", file=__import__("sys").stderr, flush=True)
+    ok = _cpu_group_ok(ok, owner.device, group)            # also: nobody starts the test before everybody has attached
+    if ok:
+        try:
+            n = 257
+            mine = torch.arange(n, device=owner.device, dtype=torch.float32) + 1000.0 * (rank + 1)
+            got = owner.allgather_fitness(mine).cpu()
+            owner.sync()
+            want = torch.cat([torch.arange(n, dtype=torch.float32) + 1000.0 * (r + 1) for r in range(world)])
+            ok = bool(torch.equal(got, want))
+        except Exception as exc:
+            ok = False
+            print(f"[ses] rank {rank}: peer-store self-test failed ({exc})", file=__import__("sys").stderr, flush=True)
+        ok = _cpu_group_ok(ok, owner.device, group)
+    if not ok:
+        try:
+            owner.comm_p2p_detach()
+        except Exception:
+            pass
+    return ok
+
+
+def _attach_rccl(owner, rank, world, group):
+    from .device import HipES
+    ok = 1
+    try:
+        box = [HipES.comm_unique_id() if rank == 0 else None]
+    except Exception as exc:                         # librccl not loadable, ...
+        ok, box = 0, [None]
+        print(f"[ses] rank {rank}: RCCL unavailable ({exc}); falling back to torch.distributed", flush=True)
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if ok and box[0] is not None:
+        try:
+            owner.comm_init(rank, world, box[0])
+        except Exception as exc:
+            ok = 0
+            print(f"[ses] rank {rank}: ses_comm_init failed ({exc}); falling back to torch.distributed", flush=True)
+    else:
+        ok = 0
+    agreed = _cpu_group_ok(ok, owner.device, group)
+    if not agreed and ok:
+        owner.comm_destroy()
+    return agreed
 
 
 def attach_comm(dev, group=None, allow_single=False):
-    """Give the HipES handle `dev` access to an RCCL communicator spanning the process group (no-op at world 1).
-    Collective: every rank of the group must call it.  One communicator per process and group is created -- on a
-    dedicated long-lived handle bound to the same stream -- and shared by every loop of the process (bench.py builds
-    several).  If RCCL cannot be initialised on ANY rank, all ranks agree to fall back to torch.distributed's
-    all-gather, which is reported (comm_info() world = 0) instead of failing the run.
-    Returns True when the library's communicator is the data path."""
+    """Give the HipES handle `dev` access to the library's all-gather over the process group (no-op at world 1).
+    Collective: every rank of the group must call it.  One dedicated long-lived handle per process and group, bound to
+    the same stream, owns the transports and is shared by every loop of the process (bench.py builds several):
+      * the peer-store transport (ranks on one node, any backend -- ranks may even share a GPU, which is how the
+        single-GPU tests drive it); verified by one checked exchange before it is used;
+      * an RCCL communicator when the backend is "nccl" (shards beyond the mailbox size, or no peer stores).
+    If neither can be set up on ALL ranks, every rank falls back to torch.distributed's all-gather, which is reported
+    (comm_transport() == "torch") instead of failing the run.  Returns True when the library carries the data path."""
     if not _dist_on() or (dist.get_world_size(group) == 1 and not allow_single):   # allow_single: the 1-GPU test of this path
-        return False
-    if dist.get_backend(group) != "nccl":           # ranks may share a GPU: keep the staged gloo path
         return False
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     key = (id(group) if group is not None else 0, world)
     owner = _COMM.get(key)
     if owner is None:
         from .device import HipES
-        ok = 1
-        try:
-            owner = HipES(None, dev.S, dev.A, dev.discrete, dev.gru, device=dev.device.index)
-            box = [HipES.comm_unique_id() if rank == 0 else None]
-        except Exception as exc:                     # librccl not loadable, ...
-            ok, box, owner = 0, [None], None
-            print(f"[ses] rank {rank}: RCCL unavailable ({exc}); falling back to torch.distributed", flush=True)
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        if ok and box[0] is not None:
-            try:
-                owner.comm_init(rank, world, box[0])
-            except Exception as exc:
-                ok = 0
-                print(f"[ses] rank {rank}: ses_comm_init failed ({exc}); falling back to torch.distributed", flush=True)
-        else:
-            ok = 0
-        flag = torch.tensor([ok], device=dev.device, dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)      # one rank failed -> nobody uses the communicator
-        if int(flag.item()) == 1:
-            _COMM[key] = owner
-        else:
-            if owner is not None:
-                owner.close()
-            owner = _COMM[key] = False
+        owner = HipES(None, dev.S, dev.A, dev.discrete, dev.gru, device=dev.device.index)
+        have_p2p = _attach_p2p(owner, rank, world, group)
+        have_rccl = dist.get_backend(group) == "nccl" and _attach_rccl(owner, rank, world, group)   # ranks sharing a GPU: never
+        if not (have_p2p or have_rccl):
+            owner.close()
+            owner = False
+        _COMM[key] = owner
     if owner is False or owner.stream.cuda_stream != dev.stream.cuda_stream:
         dev._comm_owner = None
         return False
@@ -71,9 +132,20 @@ def attach_comm(dev, group=None, allow_single=False):
 
 
 def comm_info(dev):
-    """(rank, world, rccl_version) of the communicator that carries `dev`'s all-gathers; world 0 = torch.distributed route."""
+    """(rank, world, rccl_version) of the RCCL communicator behind `dev`'s all-gathers; world 0 = none."""
     owner = getattr(dev, "_comm_owner", None) or dev
     return owner.comm_info()
+
+
+def comm_transport(dev, per_rank=1):
+    """What carries `dev`'s fitness all-gather for shards of per_rank floats: "p2p-store", "rccl" or "torch"."""
+    owner = getattr(dev, "_comm_owner", None)
+    if owner is None:
+        return "torch"
+    world, cap, _ = owner.comm_p2p_info()
+    if world and per_rank <= cap:
+        return "p2p-store"
+    return "rccl" if owner.comm_info()[1] else "torch"
 
 
 class Shard:
@@ -99,8 +171,9 @@ class Shard:
         owner = getattr(dev, "_comm_owner", None) if dev is not None else None
         if owner is None and dev is not None and dev.comm_info()[1] == self.world:
             owner = dev                                                  # a handle that was given its own communicator
-        if owner is not None and owner.comm_info()[1] == self.world:
-            out = owner.allgather_fitness(slot.contiguous())            # ses_allgather_fitness: RCCL, handle's stream
+        if owner is not None and ((owner.comm_p2p_info()[0] == self.world and self.per_rank <= owner.comm_p2p_info()[1])
+                                  or owner.comm_info()[1] == self.world):
+            out = owner.allgather_fitness(slot.contiguous())            # ses_allgather_fitness: peer stores or RCCL
         elif local.is_cuda and dist.get_backend(self.group) == "gloo":
             # test rigs only (several ranks sharing one GPU): stage the 4*N bytes through the host
             out = local.new_empty(self.per_rank * self.world)

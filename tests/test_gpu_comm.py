@@ -1,9 +1,10 @@
-"""The fitness all-gather of the C ABI (ses_comm_* / ses_allgather_fitness, RCCL on the handle's stream).
+"""The fitness all-gather of the C ABI (ses_comm_* / ses_allgather_fitness on the handle's stream): RCCL, and the
+peer-store transport's argument checks (its data path runs in tests/test_gpu_multirank.py, ranks sharing the GPU).
 
 On the 1-GPU test box RCCL can only form a one-rank communicator (it refuses two ranks on one device), which still
 runs the library's whole RCCL path -- dlopen, ncclGetUniqueId, ncclCommInitRank, ncclAllGather on the handle's
-stream, ncclCommDestroy.  With two or more GPUs visible the second test runs the sharded generation loop over a real
-two-rank communicator and compares it bit for bit with one rank."""
+stream, ncclCommDestroy.  With two or more GPUs visible the last test runs the sharded generation loop over two real
+ranks, once per transport, and compares it bit for bit with one rank."""
 import ctypes
 import os
 import socket
@@ -60,6 +61,20 @@ def test_raw_abi_comm_error_paths():
     x = torch.zeros(8, device="cuda")
     assert lib.ses_allgather_fitness(h, ctypes.c_void_p(x.data_ptr()), 8, ctypes.c_void_p(x.data_ptr())) == -1
     assert b"no communicator" in lib.ses_last_error()
+    # peer-store transport: argument checks, life cycle of a mailbox nobody else maps
+    hb = ctypes.create_string_buffer(_lib.COMM_P2P_HANDLE_BYTES)
+    assert lib.ses_comm_p2p_export(h, 0, 1, 4096, hb) == -1           # world < 2
+    assert lib.ses_comm_p2p_export(h, 2, 2, 4096, hb) == -1           # rank outside the world
+    assert lib.ses_comm_p2p_export(h, 0, 17, 4096, hb) == -1          # more ranks than a node has GPUs
+    assert lib.ses_comm_p2p_export(h, 0, 2, 0, hb) == -1
+    assert lib.ses_comm_p2p_attach(h, hb) == -1                       # nothing exported yet
+    w, m, x_ = ctypes.c_int32(-1), ctypes.c_int32(-1), ctypes.c_int32(-1)
+    assert lib.ses_comm_p2p_info(h, ctypes.byref(w), ctypes.byref(m), ctypes.byref(x_)) == 0 and w.value == 0
+    assert lib.ses_comm_p2p_export(h, 0, 2, 4097, hb) == 0 and any(hb.raw)
+    assert lib.ses_comm_p2p_export(h, 0, 2, 4096, hb) == -1           # one mailbox per handle
+    assert lib.ses_comm_p2p_info(h, ctypes.byref(w), None, None) == 0 and w.value == 0    # exported, not attached
+    assert lib.ses_allgather_fitness(h, ctypes.c_void_p(x.data_ptr()), 8, ctypes.c_void_p(x.data_ptr())) == -1
+    assert lib.ses_comm_p2p_detach(h) == 0 and lib.ses_comm_p2p_detach(h) == 0
     assert lib.ses_destroy(h) == 0
 
 
@@ -116,8 +131,10 @@ WORKER = textwrap.dedent("""
                "strategy": {"name": name, "init_sigma": 0.5, "sigma_decay": 0.99, "learning_rate": 0.05,
                             "elite_num": 8, "offspring_num": n, "seed": 5}}
         loop = builder.build_loop(cfg, 4, 1, 3, False, 10 ** 9)
-        from ses.parallel import comm_info
+        from ses.parallel import comm_info, comm_transport
         assert comm_info(loop.dev)[1] == (world if world > 1 else 0)
+        if world > 1:
+            assert comm_transport(loop.dev) == ("rccl" if os.environ.get("SES_COMM_P2P") == "0" else "p2p-store")
         fits = []
         orig = loop.rollout
         loop.rollout = lambda pop, _o=orig: (fits.append(_o(pop).cpu().numpy().copy()) or torch.from_numpy(fits[-1]).cuda())
@@ -133,7 +150,8 @@ WORKER = textwrap.dedent("""
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
-def test_two_gpus_over_rccl_equal_one_gpu_bitwise(tmp_path):
+@pytest.mark.parametrize("p2p", ["1", "0"], ids=["peer_stores_over_xgmi", "rccl"])
+def test_two_gpus_equal_one_gpu_bitwise(tmp_path, p2p):
     script = tmp_path / "w.py"
     script.write_text(WORKER % (ROOT, SRC))
     with socket.socket() as s:
@@ -143,7 +161,7 @@ def test_two_gpus_over_rccl_equal_one_gpu_bitwise(tmp_path):
     assert one.returncode == 0, one.stdout + one.stderr
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), str(tmp_path)],
-                         capture_output=True, text=True, timeout=900)
+                         capture_output=True, text=True, timeout=900, env={**os.environ, "SES_COMM_P2P": p2p})
     assert two.returncode == 0, two.stdout + two.stderr
     for name in ("openai_es", "simple_evolution", "simple_genetic"):
         ref = np.load(tmp_path / f"{name}_w1_r0.npz")
