@@ -258,6 +258,7 @@ int ses_comm_p2p_export(ses_handle *h, int32_t rank, int32_t world, int32_t max_
         return set_error(SES_ERR_COMM, "ses_comm_p2p_export: no fine-grained device memory for the mailbox: %s", hipGetErrorString(e));
     }
     e = hipMemset(p->own, 0, p->bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();                  // zeroed before any peer can learn the handle
     if (e == hipSuccess) e = hipHostMalloc((void **)&p->err_host, sizeof(uint32_t), hipHostMallocMapped);
     if (e == hipSuccess) { *p->err_host = 0u; e = hipHostGetDevicePointer((void **)&p->err_dev, p->err_host, 0); }
     hipIpcMemHandle_t ipc;
