@@ -218,6 +218,15 @@ def rollout_walker(theta, init, E, max_step=300, *, gru=False):
     return fit, ep_ret, ep_steps
 
 
+def toi_probe(body, edge, start, end):
+    """b2TimeOfImpact of lander body `body`'s polygon swept from start = (cx, cy, angle) to end against edge = (x1, y1, x2,
+    y2): (state, t) with state 0 failed / 1 overlapped / 2 touching / 3 separated"""
+    t = ctypes.c_float(0.0)
+    e, a, b = _f32(edge), _f32(start), _f32(end)
+    state = lib().o_toi_probe(int(body), _p(e), _p(a), _p(b), ctypes.byref(t))
+    return int(state), float(t.value)
+
+
 class WalkerSim:
     """one BipedalWalker-v3 env driven step by step"""
 

@@ -114,7 +114,7 @@ struct ContactTmp {                  // b2ContactVelocityConstraint, alive for o
 
 // World description: D provides
 //   static constexpr int NB, NJ, NSLOT (power of two), FIRST_SOLVED (bodies >= this have their contacts solved; body 0 =
-//   hull: touching the terrain ends the episode), VEL_ITERS, POS_ITERS; static constexpr bool PACK_MANIFOLDS
+//   hull: touching the terrain ends the episode), VEL_ITERS, POS_ITERS; static constexpr bool PACK_MANIFOLDS, CONTINUOUS
 //   static const Poly *poly(); static const BodyDef *body(); static const JointDef *joint();
 template <class D>
 struct World {
@@ -313,10 +313,9 @@ B2_FN void collide_edge_polygon(const Poly &P, const Xf &xf, const float (&wx)[6
 // T: terrain with  int n_edges() const;  int index_of(float x) const  (edge containing x, unclamped);
 //                  void edge(int k, float &x1, float &y1, float &x2, float &y2) const.
 template <class D, class T>
-B2_FN void collide(World<D> &w, const T &terr)
+B2_FN void collide_body(World<D> &w, const T &terr, const int b)
 {
-    B2_UNROLL
-    for (int b = 0; b < D::NB; ++b) {
+    {
         const Poly &P = D::poly()[b];
         const BodyDef &bd = D::body()[b];
         xf_of(w.body[b], bd, w.xf[b]);
@@ -350,7 +349,7 @@ B2_FN void collide(World<D> &w, const T &terr)
                     if (tmp.count > 0) w.game_over = true;
                 }
             }
-            continue;
+            return;
         }
         k_hi = k_hi > k_lo + D::NSLOT - 1 ? k_lo + D::NSLOT - 1 : k_hi;
         B2_UNROLL
@@ -387,6 +386,13 @@ B2_FN void collide(World<D> &w, const T &terr)
             if (m.count > 0 && !still) w.ground_contact[b] = true;                             // BeginContact
         }
     }
+}
+
+template <class D, class T>
+B2_FN void collide(World<D> &w, const T &terr)
+{
+    B2_UNROLL
+    for (int b = 0; b < D::NB; ++b) collide_body(w, terr, b);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -688,7 +694,7 @@ B2_FN void contact_solve_velocity(Manifold &m, const ContactTmp &t, Body &B, con
 }
 
 // b2ContactSolver::SolvePositionConstraints for one manifold; returns its minimum separation
-B2_FN float contact_solve_position(const Manifold &m, Body &B, const BodyDef &bd)
+B2_FN float contact_solve_position(const Manifold &m, Body &B, const BodyDef &bd, const float baumgarte = BAUMGARTE)
 {
     float min_separation = 0.0f;
     const float mB = bd.inv_mass, iB = bd.inv_i;
@@ -714,7 +720,7 @@ B2_FN float contact_solve_position(const Manifold &m, Body &B, const BodyDef &bd
             }
             const float rbx = ptx - B.cx, rby = pty - B.cy;
             min_separation = b2min(min_separation, separation);
-            const float C = b2clamp(BAUMGARTE * (separation + LINEAR_SLOP), -MAX_LINEAR_CORRECTION, 0.0f);
+            const float C = b2clamp(baumgarte * (separation + LINEAR_SLOP), -MAX_LINEAR_CORRECTION, 0.0f);
             const float rn = rbx * ny - rby * nx;
             const float K = mB + iB * rn * rn;
             const float impulse = K > 0.0f ? -C / K : 0.0f;
@@ -725,6 +731,10 @@ B2_FN float contact_solve_position(const Manifold &m, Body &B, const BodyDef &bd
     }
     return min_separation;
 }
+
+}  // namespace b2l
+#include "ses_b2_toi.h"
+namespace b2l {
 
 // ------------------------------------------------------------------------------------------------------------------
 // b2World::Step(dt, D::VEL_ITERS, D::POS_ITERS)
@@ -828,9 +838,159 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
     if (min_sleep >= TIME_TO_SLEEP && position_solved) w.awake = false;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// b2World::SolveTOI for worlds whose only static geometry is the terrain and whose dynamic bodies do not collide with
+// each other: every TOI event concerns ONE body and the terrain edges near it.  After the discrete solve each body has
+// a sweep (start of step -> solved end of step); while some (body, candidate edge) pair reaches the target separation
+// before the end of the step, the earliest such body is rolled back to that time, its manifolds are updated
+// (b2Contact::Update: begin / end events fire here too -- a hull that touches ends the episode), and b2Island::SolveTOI
+// runs on it alone: up to 20 position iterations against its touching manifolds with b2_toiBaugarte, the sweep
+// restarts there ("leap of faith"), the contacts' velocity rows are solved from zero impulses for all velocity
+// iterations (joints are ignored in a sub-step, as in Box2D: their error is repaired by the next step), and the body
+// moves on for the rest of the step with the velocity it is left with.  Impulses of a sub-step are not kept.
+// Box2D caches a contact's TOI until one of its bodies moves; here every pair is re-evaluated after an event.
+constexpr float TOI_BAUMGARTE = 0.75f;
+constexpr int TOI_MAX_SUBSTEPS = 8;                  // b2_maxSubSteps, per contact and step
+
+template <class D, class T>
+B2_FN void world_solve_toi(World<D> &w, const T &terr, Sweep (&sw)[D::NB], float dt)
+{
+    int toi_count[D::NB][D::NSLOT];
+    bool disabled[D::NB][D::NSLOT];
+    B2_UNROLL
+    for (int b = 0; b < D::NB; ++b) {
+        B2_UNROLL
+        for (int s = 0; s < D::NSLOT; ++s) { toi_count[b][s] = 0; disabled[b][s] = false; }
+    }
+    for (int ev = 0; ev < D::NB * D::NSLOT * TOI_MAX_SUBSTEPS; ++ev) {
+        float min_alpha = 1.0f;
+        int min_b = -1, min_s = -1;
+        B2_UNROLL
+        for (int b = 0; b < D::NB; ++b) {
+            const Poly &P = D::poly()[b];
+            const BodyDef &bd = D::body()[b];
+            // fattened AABB of the swept polygon (b2Fixture::Synchronize: the proxy covers both ends of the sweep)
+            float xmin = FLT_BIG, xmax = -FLT_BIG, ymin = FLT_BIG;
+            B2_UNROLL
+            for (int e = 0; e < 2; ++e) {
+                Xf xf;
+                sweep_xf(sw[b], bd, e ? 1.0f : 0.0f, xf);
+                B2_UNROLL
+                for (int i = 0; i < 6; ++i) {
+                    if (i < P.n) {
+                        const float x = (xf.c * P.vx[i] - xf.s * P.vy[i]) + xf.px, y = (xf.s * P.vx[i] + xf.c * P.vy[i]) + xf.py;
+                        xmin = b2min(xmin, x); xmax = b2max(xmax, x); ymin = b2min(ymin, y);
+                    }
+                }
+            }
+            int k_lo = terr.index_of(xmin - AABB_EXTENSION), k_hi = terr.index_of(xmax + AABB_EXTENSION);
+            k_lo = k_lo < 0 ? 0 : k_lo;
+            k_hi = k_hi > terr.n_edges() - 1 ? terr.n_edges() - 1 : k_hi;
+            k_hi = k_hi > k_lo + D::NSLOT - 1 ? k_lo + D::NSLOT - 1 : k_hi;
+            B2_UNROLL
+            for (int s = 0; s < D::NSLOT; ++s) {
+                const int k = k_lo + ((s - k_lo) & (D::NSLOT - 1));
+                if (k <= k_hi && k_lo <= k_hi && !disabled[b][s] && toi_count[b][s] <= TOI_MAX_SUBSTEPS) {
+                    ToiPair pr;
+                    terr.edge(k, pr.ex[0], pr.ey[0], pr.ex[1], pr.ey[1]);
+                    pr.P = &P;
+                    if (!(ymin - AABB_EXTENSION > b2max(pr.ey[0], pr.ey[1]))) {
+                        float t;
+                        const int state = time_of_impact(pr, sw[b], bd, t);
+                        const float alpha = state == TOI_TOUCHING ? b2min(sw[b].alpha0 + (1.0f - sw[b].alpha0) * t, 1.0f) : 1.0f;
+                        if (alpha < min_alpha) { min_alpha = alpha; min_b = b; min_s = s; }
+                    }
+                }
+            }
+        }
+        if (min_b < 0 || 1.0f - 10.0f * 1.1920928955078125e-7f < min_alpha) break;
+        bool stop = false;
+        B2_UNROLL
+        for (int b = 0; b < D::NB; ++b) {
+            if (b == min_b) {
+                const BodyDef &bd = D::body()[b];
+                const Sweep backup = sw[b];
+                sweep_advance(sw[b], min_alpha);
+                w.body[b].cx = sw[b].c0x; w.body[b].cy = sw[b].c0y; w.body[b].a = sw[b].a0;
+                collide_body(w, terr, b);                                    // b2Contact::Update at the time of impact
+                bool touching = false;
+                B2_UNROLL
+                for (int s = 0; s < D::NSLOT; ++s) {
+                    if (s == min_s) {
+                        toi_count[b][s] += 1;
+                        if (b >= D::FIRST_SOLVED) touching = w.mf[b >= D::FIRST_SOLVED ? b - D::FIRST_SOLVED : 0][s].count > 0;
+                    }
+                }
+                if (b < D::FIRST_SOLVED) {
+                    // the hull: a touch has just ended the episode (collide_body set game_over); whatever a sub-step
+                    // would do to it is never observed
+                    touching = w.game_over;
+                    stop = touching;
+                }
+                if (!touching) {                                             // "the contact is not touching at the TOI": disabled for this step
+                    B2_UNROLL
+                    for (int s = 0; s < D::NSLOT; ++s) {
+                        if (s == min_s) disabled[b][s] = true;
+                    }
+                    sw[b] = backup;
+                    w.body[b].cx = sw[b].cx; w.body[b].cy = sw[b].cy; w.body[b].a = sw[b].a;
+                } else if (b >= D::FIRST_SOLVED) {
+                    // b2Island::SolveTOI on this body alone
+                    const int bi = b >= D::FIRST_SOLVED ? b - D::FIRST_SOLVED : 0;
+                    Body &B = w.body[b];
+                    for (int i = 0; i < 20; ++i) {
+                        float min_separation = 0.0f;
+                        B2_UNROLL
+                        for (int s = 0; s < D::NSLOT; ++s)
+                            min_separation = b2min(min_separation, contact_solve_position(w.mf[bi][s], B, bd, TOI_BAUMGARTE));
+                        if (min_separation >= -1.5f * LINEAR_SLOP) break;
+                    }
+                    sw[b].c0x = B.cx; sw[b].c0y = B.cy; sw[b].a0 = B.a;     // leap of faith to the new safe state
+                    Xf xf;
+                    xf_of(B, bd, xf);
+                    Manifold mt[D::NSLOT];
+                    ContactTmp ct[D::NSLOT];
+                    B2_UNROLL
+                    for (int s = 0; s < D::NSLOT; ++s) {
+                        mt[s] = w.mf[bi][s];
+                        mt[s].ni[0] = 0.0f; mt[s].ni[1] = 0.0f; mt[s].ti[0] = 0.0f; mt[s].ti[1] = 0.0f;   // no warm starting
+                        contact_init(mt[s], ct[s], B, bd, xf);
+                    }
+                    for (int it = 0; it < D::VEL_ITERS; ++it) {
+                        B2_UNROLL
+                        for (int s = 0; s < D::NSLOT; ++s) contact_solve_velocity(mt[s], ct[s], B, bd);
+                    }
+                    const float h = (1.0f - min_alpha) * dt;
+                    const float trx = h * B.vx, try_ = h * B.vy;
+                    if (trx * trx + try_ * try_ > MAX_TRANSLATION_SQ) {
+                        const float ratio = MAX_TRANSLATION / B2_SQRT(trx * trx + try_ * try_);
+                        B.vx *= ratio; B.vy *= ratio;
+                    }
+                    const float rot = h * B.w;
+                    if (rot * rot > MAX_ROTATION_SQ) {
+                        const float ratio = MAX_ROTATION / b2abs(rot);
+                        B.w *= ratio;
+                    }
+                    B.cx += h * B.vx; B.cy += h * B.vy;
+                    B.a += h * B.w;
+                    sw[b].cx = B.cx; sw[b].cy = B.cy; sw[b].a = B.a;
+                }
+            }
+        }
+        if (stop) break;
+    }
+}
+
 template <class D, class T>
 B2_FN void world_step(World<D> &w, const T &terr, float dt)
 {
+    Sweep sw[D::NB];
+    if constexpr (D::CONTINUOUS) {
+        B2_UNROLL
+        for (int b = 0; b < D::NB; ++b) {
+            sw[b].c0x = w.body[b].cx; sw[b].c0y = w.body[b].cy; sw[b].a0 = w.body[b].a; sw[b].alpha0 = 0.0f;
+        }
+    }
     collide(w, terr);
 
     // b2Island::Solve: integrate velocities (gravity, no damping: v *= 1 / (1 + h * 0) is exact)
@@ -886,6 +1046,13 @@ B2_FN void world_step(World<D> &w, const T &terr, float dt)
                 }
                 n += touching ? 1 : 0;
             }
+        }
+    }
+    if constexpr (D::CONTINUOUS) {
+        if (w.awake) {
+            B2_UNROLL
+            for (int b = 0; b < D::NB; ++b) { sw[b].cx = w.body[b].cx; sw[b].cy = w.body[b].cy; sw[b].a = w.body[b].a; }
+            world_solve_toi(w, terr, sw, dt);
         }
     }
 }

@@ -11,6 +11,7 @@ void o_philox_raw(const uint32_t *ctr, const uint32_t *key, uint32_t *out);
 }
 
 #define B2_FN static inline
+#define B2_NOINLINE static __attribute__((noinline))
 #define B2_FN_MEMBER inline
 #define B2_CONST static const
 #define B2_UNROLL
@@ -106,6 +107,20 @@ void o_lander_debug(const void *state, float *bodies, int32_t *ints)
     for (int b = 0; b < 3; ++b)
         for (int k = 0; k < 2; ++k) touching += b >= 1 ? s->env.w.mf[b - 1][k].count : 0;
     ints[7] = touching;
+}
+
+// time of impact of a lander body's polygon (0 = hull, 1 / 2 = legs) swept from (c0, a0) to (c1, a1) against the edge
+// e = (x1, y1, x2, y2); returns the b2TOIOutput state (0 failed, 1 overlapped, 2 touching, 3 separated), *t = fraction
+int o_toi_probe(int body, const float *e, const float *c0a0, const float *c1a1, float *t)
+{
+    ToiPair pr;
+    pr.ex[0] = e[0]; pr.ey[0] = e[1]; pr.ex[1] = e[2]; pr.ey[1] = e[3];
+    pr.P = &LANDER_POLY[body];
+    Sweep sw;
+    sw.c0x = c0a0[0]; sw.c0y = c0a0[1]; sw.a0 = c0a0[2];
+    sw.cx = c1a1[0]; sw.cy = c1a1[1]; sw.a = c1a1[2];
+    sw.alpha0 = 0.0f;
+    return time_of_impact(pr, sw, LANDER_BODY[body], *t);
 }
 
 // ---- BipedalWalker-v3 ----

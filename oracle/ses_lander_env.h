@@ -39,6 +39,7 @@ B2_CONST JointDef LANDER_JOINT[2] = {
 struct LanderDef {
     static constexpr int NB = 3, NJ = 2, NSLOT = 2, FIRST_SOLVED = 1, VEL_ITERS = 6 * 30, POS_ITERS = 2 * 30;
     static constexpr bool PACK_MANIFOLDS = false;    // 2 x 2 slots: the solver runs over them as they are
+    static constexpr bool CONTINUOUS = true;         // b2World::SolveTOI against the terrain (ses_b2.h)
     static constexpr float GRAVITY_Y = -10.0f;
     B2_FN const Poly *poly() { return LANDER_POLY; }
     B2_FN const BodyDef *body() { return LANDER_BODY; }

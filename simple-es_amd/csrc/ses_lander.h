@@ -14,6 +14,7 @@
 #include "ses_rng.h"
 
 #define B2_FN static __device__ __forceinline__
+#define B2_NOINLINE static __device__ __attribute__((noinline))
 #define B2_FN_MEMBER __device__ __forceinline__
 #define B2_CONST static __device__ const
 #define B2_UNROLL _Pragma("unroll")

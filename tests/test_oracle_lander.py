@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_world_and_env_headers_are_one_text_in_oracle_and_product():
     # the oracle and the product compile the same text (host / gfx950); see the header of ses_b2.h
-    for name in ("ses_b2.h", "ses_lander_env.h", "ses_b2_shapes.h"):
+    for name in ("ses_b2.h", "ses_b2_toi.h", "ses_lander_env.h", "ses_b2_shapes.h"):
         assert filecmp.cmp(os.path.join(ROOT, "oracle", name), os.path.join(ROOT, "simple-es_amd", "csrc", name), shallow=False), name
 
 
@@ -158,3 +158,69 @@ def test_resting_contact_is_quiet():
     assert done and r == 100.0                                     # asleep: every body below the sleep tolerances for 0.5 s
     assert len(speeds) > 25 and max(speeds[-20:]) < 0.02
     assert abs(obs[1]) < 0.01 and abs(obs[4]) < 0.05
+
+
+def test_time_of_impact_against_independent_geometry():
+    """b2TimeOfImpact restated (oracle/ses_b2_toi.h): for a leg box swept towards a flat edge the returned fraction is the
+    time at which the lowest vertex is `target` = linearSlop above the edge line, to the tolerance of a quarter slop --
+    checked with nothing but the box's corners; translation has a closed form."""
+    hx, hy = 2 / 30, 8 / 30                                            # LEG_W, LEG_H half extents (lunar_lander.py)
+    flat = (-5.0, 0.0, 5.0, 0.0)
+    for y0, y1 in ((0.30, 0.20), (0.28, 0.27), (0.9, -0.4), (2.0, 0.0)):
+        state, t = co.toi_probe(1, flat, (0, y0, 0), (0, y1, 0))
+        assert state == 2 and abs(t - ((y0 - hy) - 0.005) / (y0 - y1)) < 0.00125 / (y0 - y1) + 1e-6, (y0, y1, state, t)
+    for y0, y1 in ((1.0, 0.5), (1.0, 0.9), (0.3, 0.28)):
+        assert co.toi_probe(1, flat, (0, y0, 0), (0, y1, 0)) == (3, 1.0)            # never closer than the target: separated
+    assert co.toi_probe(1, flat, (0, 0.2, 0), (0, 0.1, 0))[0] == 1                  # starts inside the edge: overlapped
+    rng = np.random.RandomState(4)
+    corners = np.array([[-hx, -hy], [hx, -hy], [hx, hy], [-hx, hy]])
+    hits = 0
+    for _ in range(300):
+        c0 = np.array([rng.uniform(-1, 1), rng.uniform(0.35, 1.5), rng.uniform(-1.5, 1.5)])
+        c1 = c0 + np.array([rng.uniform(-0.5, 0.5), rng.uniform(-1.5, 0.1), rng.uniform(-1.0, 1.0)])
+        state, t = co.toi_probe(1, flat, c0.astype(np.float32), c1.astype(np.float32))
+
+        def lowest(tt):
+            c = (1 - tt) * c0 + tt * c1
+            rot = np.array([[np.cos(c[2]), -np.sin(c[2])], [np.sin(c[2]), np.cos(c[2])]])
+            return (corners @ rot.T)[:, 1].min() + c[1]
+        if state == 2:
+            hits += 1
+            assert abs(lowest(t) - 0.005) < 0.00125 + 2e-5, (c0, c1, t, lowest(t))
+            assert min(lowest(tt) for tt in np.linspace(0, t, 50)) > 0.005 - 0.0013    # and it is the FIRST such time
+        else:
+            assert state == 3 and min(lowest(tt) for tt in np.linspace(0, 1, 200)) > 0.005 - 0.0013, (c0, c1, state)
+    assert 100 < hits < 290
+
+
+def test_continuous_collision_stops_fast_legs_at_the_surface():
+    """Free fall from the top of the screen reaches ~7 m/s = 0.14 m per step, half a leg: without b2World::SolveTOI the
+    legs would be found inside the terrain; with it no leg corner is ever deeper than Box2D's allowed penetration
+    (3 * linearSlop) plus what one step's position correction moves."""
+    rng = np.random.RandomState(8)
+    sim = co.LanderSim()
+    hx, hy = 2 / 30, 8 / 30
+    corners = np.array([[-hx, -hy], [hx, -hy], [hx, hy], [-hx, hy]])
+    deepest, speeds = 0.0, []
+    for _ in range(6):
+        u = rng.rand(16).astype(np.float32)
+        sim.reset(u)
+        heights = None
+        done = False
+        while not done:
+            b_before, _ = sim.debug()
+            _, _, done = sim.step(0.0, 0.0)
+            b, info = sim.debug()
+            speeds.append(float(np.abs(b_before[:, 4]).max()))
+            if done:
+                break                                                  # the hull's own impact ends the episode and the sub-stepping
+            for leg in (1, 2):
+                c = b[leg]
+                rot = np.array([[np.cos(c[2]), -np.sin(c[2])], [np.sin(c[2]), np.cos(c[2])]])
+                low = (corners @ rot.T + c[:2])
+                # terrain under the landing pad is flat at helipad_y = H / 4; only count corners above the flat part
+                on_pad = np.abs(low[:, 0] - 10.0) < 1.9
+                if on_pad.any():
+                    deepest = max(deepest, float((0.99 * 13.333 / 4 - low[on_pad, 1]).max()))   # smoothed pad height
+    assert max(speeds) > 4.0                                           # these ARE fast impacts
+    assert deepest < 0.04, deepest
