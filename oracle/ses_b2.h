@@ -869,8 +869,10 @@ B2_FN void world_solve_toi(World<D> &w, const T &terr, Sweep (&sw)[D::NB], float
         for (int b = 0; b < D::NB; ++b) {
             const Poly &P = D::poly()[b];
             const BodyDef &bd = D::body()[b];
-            // fattened AABB of the swept polygon (b2Fixture::Synchronize: the proxy covers both ends of the sweep)
+            // fattened AABB of the swept polygon (b2Fixture::Synchronize: the proxy covers both ends of the sweep);
+            // (sx, sy): the polygon's vertices at the start of the sweep, r_max: the farthest vertex from the centre of mass
             float xmin = FLT_BIG, xmax = -FLT_BIG, ymin = FLT_BIG;
+            float sx[6], sy[6], sx0 = FLT_BIG, sx1 = -FLT_BIG, sy0 = FLT_BIG, sy1 = -FLT_BIG, r_max_sq = 0.0f;
             B2_UNROLL
             for (int e = 0; e < 2; ++e) {
                 Xf xf;
@@ -880,9 +882,27 @@ B2_FN void world_solve_toi(World<D> &w, const T &terr, Sweep (&sw)[D::NB], float
                     if (i < P.n) {
                         const float x = (xf.c * P.vx[i] - xf.s * P.vy[i]) + xf.px, y = (xf.s * P.vx[i] + xf.c * P.vy[i]) + xf.py;
                         xmin = b2min(xmin, x); xmax = b2max(xmax, x); ymin = b2min(ymin, y);
+                        if (e == 0) {
+                            sx[i] = x; sy[i] = y;
+                            sx0 = b2min(sx0, x); sx1 = b2max(sx1, x); sy0 = b2min(sy0, y); sy1 = b2max(sy1, y);
+                            const float rx = P.vx[i] - bd.lcx, ry = P.vy[i] - bd.lcy;
+                            r_max_sq = b2max(r_max_sq, rx * rx + ry * ry);
+                        }
+                    } else if (e == 0) {
+                        sx[i] = 0.0f; sy[i] = 0.0f;
                     }
                 }
             }
+            // A pair that cannot come out of b2TimeOfImpact as "touching" is not evaluated (every other outcome leaves
+            // alpha at 1).  No point of the polygon moves farther during the sweep than the centre's path plus r_max
+            // times the turn (`reach`); at the start of the sweep the shapes are at least as far apart as (i) their
+            // boxes and (ii) the polygon is from the edge's line, measured along the line's normal.  If that lower
+            // bound exceeds reach + target + tolerance, the separation stays above target + tolerance for the whole
+            // sweep.  This is what keeps a lander in flight and, above all, one RESTING on its legs (core shapes
+            // 0.015 apart, not moving) from paying a GJK evaluation per leg, edge and step.
+            const float dcx = sw[b].cx - sw[b].c0x, dcy = sw[b].cy - sw[b].c0y;
+            const float reach = (B2_SQRT(dcx * dcx + dcy * dcy) + B2_SQRT(r_max_sq) * b2abs(sw[b].a - sw[b].a0)) +
+                                ((b2max(LINEAR_SLOP, POLY_RADIUS + POLY_RADIUS - 3.0f * LINEAR_SLOP) + 0.25f * LINEAR_SLOP) + 2.0e-4f);
             int k_lo = terr.index_of(xmin - AABB_EXTENSION), k_hi = terr.index_of(xmax + AABB_EXTENSION);
             k_lo = k_lo < 0 ? 0 : k_lo;
             k_hi = k_hi > terr.n_edges() - 1 ? terr.n_edges() - 1 : k_hi;
@@ -894,7 +914,25 @@ B2_FN void world_solve_toi(World<D> &w, const T &terr, Sweep (&sw)[D::NB], float
                     ToiPair pr;
                     terr.edge(k, pr.ex[0], pr.ey[0], pr.ex[1], pr.ey[1]);
                     pr.P = &P;
-                    if (!(ymin - AABB_EXTENSION > b2max(pr.ey[0], pr.ey[1]))) {
+                    const float gx = b2max(0.0f, b2max(sx0 - b2max(pr.ex[0], pr.ex[1]), b2min(pr.ex[0], pr.ex[1]) - sx1));
+                    const float gy = b2max(0.0f, b2max(sy0 - b2max(pr.ey[0], pr.ey[1]), b2min(pr.ey[0], pr.ey[1]) - sy1));
+                    float line_sep = 0.0f;
+                    {
+                        float nx = pr.ey[1] - pr.ey[0], ny = -(pr.ex[1] - pr.ex[0]);     // the edge's normal, either sense
+                        const float len = B2_SQRT(nx * nx + ny * ny);
+                        float lo = FLT_BIG, hi = -FLT_BIG;
+                        B2_UNROLL
+                        for (int i = 0; i < 6; ++i) {
+                            if (i < P.n) {
+                                const float d = nx * (sx[i] - pr.ex[0]) + ny * (sy[i] - pr.ey[0]);
+                                lo = b2min(lo, d); hi = b2max(hi, d);
+                            }
+                        }
+                        // all vertices on one side of the line: its distance (un-normalised d / len, rounded down a little)
+                        if (len > 1.0e-6f) line_sep = b2max(0.0f, b2max(lo, -hi)) / len * 0.999f;
+                    }
+                    const bool out_of_reach = gx * gx + gy * gy > reach * reach || line_sep > reach;
+                    if (!(ymin - AABB_EXTENSION > b2max(pr.ey[0], pr.ey[1])) && !out_of_reach) {
                         float t;
                         const int state = time_of_impact(pr, sw[b], bd, t);
                         const float alpha = state == TOI_TOUCHING ? b2min(sw[b].alpha0 + (1.0f - sw[b].alpha0) * t, 1.0f) : 1.0f;
@@ -956,9 +994,25 @@ B2_FN void world_solve_toi(World<D> &w, const T &terr, Sweep (&sw)[D::NB], float
                         mt[s].ni[0] = 0.0f; mt[s].ni[1] = 0.0f; mt[s].ti[0] = 0.0f; mt[s].ti[1] = 0.0f;   // no warm starting
                         contact_init(mt[s], ct[s], B, bd, xf);
                     }
+                    // all D::VEL_ITERS iterations, as in Box2D (subStep.velocityIterations = step.velocityIterations) -- but
+                    // an iteration that leaves the body's velocity and every accumulated impulse bit for bit where they
+                    // were is a fixed point of the map, and so are all the iterations after it: stop there.  (One body
+                    // against one or two manifolds, no joints, no warm start: that happens after ~25 iterations.)
                     for (int it = 0; it < D::VEL_ITERS; ++it) {
+                        const float vx0 = B.vx, vy0 = B.vy, w0 = B.w;
+                        float imp0[D::NSLOT][4];
+                        B2_UNROLL
+                        for (int s = 0; s < D::NSLOT; ++s) {
+                            imp0[s][0] = mt[s].ni[0]; imp0[s][1] = mt[s].ni[1]; imp0[s][2] = mt[s].ti[0]; imp0[s][3] = mt[s].ti[1];
+                        }
                         B2_UNROLL
                         for (int s = 0; s < D::NSLOT; ++s) contact_solve_velocity(mt[s], ct[s], B, bd);
+                        bool same = vx0 == B.vx && vy0 == B.vy && w0 == B.w;
+                        B2_UNROLL
+                        for (int s = 0; s < D::NSLOT; ++s)
+                            same = same && imp0[s][0] == mt[s].ni[0] && imp0[s][1] == mt[s].ni[1] && imp0[s][2] == mt[s].ti[0] &&
+                                   imp0[s][3] == mt[s].ti[1];
+                        if (same) break;
                     }
                     const float h = (1.0f - min_alpha) * dt;
                     const float trx = h * B.vx, try_ = h * B.vy;
@@ -982,9 +1036,8 @@ B2_FN void world_solve_toi(World<D> &w, const T &terr, Sweep (&sw)[D::NB], float
 }
 
 template <class D, class T>
-B2_FN void world_step(World<D> &w, const T &terr, float dt)
+B2_FN void world_step_discrete(World<D> &w, const T &terr, float dt, Sweep (&sw)[D::NB])
 {
-    Sweep sw[D::NB];
     if constexpr (D::CONTINUOUS) {
         B2_UNROLL
         for (int b = 0; b < D::NB; ++b) {
@@ -1049,12 +1102,30 @@ B2_FN void world_step(World<D> &w, const T &terr, float dt)
         }
     }
     if constexpr (D::CONTINUOUS) {
-        if (w.awake) {
-            B2_UNROLL
-            for (int b = 0; b < D::NB; ++b) { sw[b].cx = w.body[b].cx; sw[b].cy = w.body[b].cy; sw[b].a = w.body[b].a; }
-            world_solve_toi(w, terr, sw, dt);
-        }
+        B2_UNROLL
+        for (int b = 0; b < D::NB; ++b) { sw[b].cx = w.body[b].cx; sw[b].cy = w.body[b].cy; sw[b].a = w.body[b].a; }
     }
+}
+
+// The two halves of b2World::Step are separate functions because the device build keeps them in separate REAL
+// functions: the discrete half holds the whole world in registers and contains no call; the continuous half works on
+// the world where it lies in memory, reads little more than the sweeps in a step without an event, and is the only one
+// that calls time_of_impact.  (As one function, the values that had to survive the call sites -- the whole world --
+// were parked in scratch memory in every step: +30 % on the lander rollout.)
+template <class D, class T>
+B2_FN void world_step_toi(World<D> &w, const T &terr, float dt, Sweep (&sw)[D::NB])
+{
+    if constexpr (D::CONTINUOUS) {
+        if (w.awake) world_solve_toi(w, terr, sw, dt);
+    }
+}
+
+template <class D, class T>
+B2_FN void world_step(World<D> &w, const T &terr, float dt)
+{
+    Sweep sw[D::NB];
+    world_step_discrete(w, terr, dt, sw);
+    world_step_toi(w, terr, dt, sw);
 }
 
 }  // namespace b2l

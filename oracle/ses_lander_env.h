@@ -100,9 +100,15 @@ B2_FN void lander_impulse(LanderEnv &e, float jx, float jy, float px, float py)
     L.w += bd.inv_i * ((px - L.cx) * jy - (py - L.cy) * jx);
 }
 
-// one env step (lunar_lander.py step()); returns the reward, sets done
+// one env step (lunar_lander.py step()); returns the reward, sets done.  In two halves (ses_b2.h, world_step_toi, says
+// why): lander_step_begin = engines + the discrete half of world.Step, lander_step_end = its continuous half + reward.
+struct LanderPending {               // what the first half hands to the second
+    Sweep sw[3];
+    float m_power, s_power;
+};
+
 template <class T>
-B2_FN float lander_step(LanderEnv &e, const T &terr, float a0, float a1, bool &done)
+B2_FN void lander_step_begin(LanderEnv &e, const T &terr, float a0, float a1, LanderPending &pd)
 {
     float d0, d1;
     B2_DISPERSION(e.key0, e.key1, e.step, d0, d1);   // two uniforms in (-1, 1), divided by SCALE below
@@ -130,7 +136,15 @@ B2_FN float lander_step(LanderEnv &e, const T &terr, float a0, float a1, bool &d
         lander_impulse(e, -ox * LL_SIDE_POWER * s_power, -oy * LL_SIDE_POWER * s_power,
                        e.posx + ox - tipx * (17.0f / LL_SCALE), e.posy + oy + tipy * (14.0f / LL_SCALE));
     }
-    world_step(e.w, terr, LL_DT);
+    world_step_discrete(e.w, terr, LL_DT, pd.sw);
+    pd.m_power = m_power; pd.s_power = s_power;
+}
+
+template <class T>
+B2_FN float lander_step_end(LanderEnv &e, const T &terr, LanderPending &pd, bool &done)
+{
+    world_step_toi(e.w, terr, LL_DT, pd.sw);
+    const float m_power = pd.m_power, s_power = pd.s_power;
     {
         Xf x;
         xf_of(e.w.body[0], LANDER_BODY[0], x);
@@ -149,6 +163,14 @@ B2_FN float lander_step(LanderEnv &e, const T &terr, float a0, float a1, bool &d
     if (e.w.game_over || b2abs(obs[0]) >= 1.0f) { done = true; reward = -100.0f; }
     if (!e.w.awake) { done = true; reward = 100.0f; }
     return reward;
+}
+
+template <class T>
+B2_FN float lander_step(LanderEnv &e, const T &terr, float a0, float a1, bool &done)
+{
+    LanderPending pd;
+    lander_step_begin(e, terr, a0, a1, pd);
+    return lander_step_end(e, terr, pd, done);
 }
 
 // reset from one row of 16 uniforms (the caller has tabulated the terrain with lander_terrain_heights).  Like gym's

@@ -45,26 +45,42 @@ constexpr int LL_TERRAIN_ROW = 12;           // floats of LDS per env: 11 height
 struct LanderState {
     b2l::LanderEnv env;
     const float *ty;                         // LDS: this env's terrain heights
+    b2l::LanderPending pend;                 // between the two halves of a step
 };
 
 __device__ __forceinline__ void ll_obs(const LanderState &s, float (&obs)[8]) { b2l::lander_obs(s.env, obs); }
 
 // One env step; returns the reward, sets done.
-// A REAL function (not inlined): a world step is ~20 000 instructions, as long as a small kernel.  Compiled once and
+// REAL functions (not inlined): a world step is ~20 000 instructions, as long as a small kernel.  Compiled once and
 // called, it gets its own register allocation -- the rollout kernels keep their policy weights in registers without
 // competing with the solver for them -- and every kernel shares one copy of the code.  The state lives in the caller's
-// private memory; it is copied into registers on entry and written back on exit (~120 values each way, next to the
-// 180 solver iterations in between).  The env code contains no wave-level operation, so the call may sit under any
-// divergence (finished envs simply do not call).
-__device__ __attribute__((noinline)) float ll_step(LanderState &s, float a0, float a1, bool &done)
+// private memory.  Two functions: ll_step copies the state into registers, runs the engines and the discrete half of
+// world.Step (180 solver iterations, no call inside) and writes it back; ll_step_end runs the continuous half
+// (b2World::SolveTOI, the only code that calls time_of_impact) and the reward on the state where it lies -- in a step
+// without an impact it touches the sweeps and a few positions.  (Both halves in one function: whatever had to survive
+// the call sites, i.e. the whole world, was parked in scratch memory every step: +30 % on the C3 rollout.)
+// The env code contains no wave-level operation, so the calls may sit under any divergence (finished envs simply do
+// not call).
+__device__ __attribute__((noinline)) float ll_step_end(LanderState &s, bool &done)
 {
-    b2l::LanderEnv e = s.env;
     const b2l::LanderTerrain terr{s.ty};
     bool d;
-    const float r = b2l::lander_step(e, terr, a0, a1, d);
-    s.env = e;
+    const float r = b2l::lander_step_end(s.env, terr, s.pend, d);
     done = d;
     return r;
+}
+
+__device__ __attribute__((noinline)) float ll_step(LanderState &s, float a0, float a1, bool &done)
+{
+    {
+        b2l::LanderEnv e = s.env;
+        const b2l::LanderTerrain terr{s.ty};
+        b2l::LanderPending pd;
+        b2l::lander_step_begin(e, terr, a0, a1, pd);
+        s.env = e;
+        s.pend = pd;
+    }
+    return ll_step_end(s, done);
 }
 
 // reset from one row of 16 uniforms; like gym's reset() it ends with one no-op step.

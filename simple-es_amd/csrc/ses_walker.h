@@ -30,21 +30,34 @@ constexpr int BW_TERRAIN_ROW = b2l::BW_TERRAIN_LENGTH;
 struct WalkerState {
     b2l::WalkerEnv env;
     const float *ty;                         // LDS: this env's terrain heights
+    b2l::WalkerPending pend;                 // between the two halves of a step
 };
 
 __device__ __forceinline__ void bw_obs(const WalkerState &s, float (&obs)[24]) { b2l::walker_obs(s.env, obs); }
 
-// one env step as a real function, like ll_step (ses_lander.h): state in the caller's private memory, no wave votes inside
-__device__ __attribute__((noinline)) float bw_step(WalkerState &s, float a0, float a1, float a2, float a3, bool &done)
+// one env step as two real functions, like ll_step / ll_step_end (ses_lander.h): state in the caller's private memory,
+// no wave votes inside
+__device__ __attribute__((noinline)) float bw_step_end(WalkerState &s, bool &done)
 {
-    b2l::WalkerEnv e = s.env;
     const b2l::WalkerTerrain terr{s.ty};
-    const float act[4] = {a0, a1, a2, a3};
     bool d;
-    const float r = b2l::walker_step(e, terr, act, d);
-    s.env = e;
+    const float r = b2l::walker_step_end(s.env, terr, s.pend, d);
     done = d;
     return r;
+}
+
+__device__ __attribute__((noinline)) float bw_step(WalkerState &s, float a0, float a1, float a2, float a3, bool &done)
+{
+    {
+        b2l::WalkerEnv e = s.env;
+        const b2l::WalkerTerrain terr{s.ty};
+        const float act[4] = {a0, a1, a2, a3};
+        b2l::WalkerPending pd;
+        b2l::walker_step_begin(e, terr, act, pd);
+        s.env = e;
+        s.pend = pd;
+    }
+    return bw_step_end(s, done);
 }
 
 // reset from one row of 4 floats ([0] force uniform, [1], [2] terrain key bit patterns); ends with one no-op step.
