@@ -476,7 +476,7 @@ def run_rank(args):
                 result["c3_lunarlander_pomdp_gru_4096"] = {
                     "rollout_ms": ms3, "env_steps": n3, "env_steps_per_s": n3 / (ms3 * 1e-3), "mean_episode_steps": n3 / (4096 * 5),
                     "env": "gym's lunar_lander.py restated on a Box2D-style world: 3 bodies, 2 revolute joints, 180 velocity + "
-                           "<= 60 position iterations per step (parity with gym / Box2D unpinned; GPU == CPU build bit for bit)",
+                           "<= 60 position iterations per step, time-of-impact sub-stepping against the terrain (parity with gym / Box2D unpinned; GPU == CPU build bit for bit)",
                     "bound": "valu issue + the latency of the sequential solver (profiles: *_sq_c3_lander.json)"}
                 c3.close()
             except Exception as exc:

@@ -18,10 +18,14 @@
 //     Box2D's own early exit, island sleep timer);
 //   * float32 throughout, IEEE division and sqrt.  Box2D's x86 build rounds every product separately; so does this
 //     file, except in the two innermost loops (joint and contact velocity iterations), which use fused multiply-adds.
-// Not restated (documented deviations): continuous collision (b2World::SolveTOI), the broad phase (every terrain edge
-// whose x-range the fattened polygon AABB overlaps is a candidate -- same touching set), Box2D's island traversal
-// order (here: joints in definition order, then contacts by body, then by manifold slot), sinf / cosf of the C
-// library (here: the build's deterministic sincos).
+//   * b2World::SolveTOI -- continuous collision against the terrain: b2Distance / b2SeparationFunction /
+//     b2TimeOfImpact (ses_b2_toi.h) per (body polygon, candidate terrain edge) pair and step, the earliest impact rolls
+//     its body back, updates its manifolds and sub-steps it alone (b2Island::SolveTOI), see world_solve_toi below.
+// Not restated (documented deviations): the broad phase (every terrain edge whose x-range the fattened polygon AABB
+// overlaps is a candidate -- same touching set), Box2D's island traversal order (here: joints in definition order, then
+// contacts by body, then by manifold slot), sinf / cosf of the C library (here: the build's deterministic sincos), the
+// per-contact TOI cache (every pair is re-evaluated after an event), a sub-step for a hull that touches (the touch ends
+// the episode; what the sub-step would do is never observed).
 //
 // All N velocity iterations are run, as in Box2D: with the light legs on the heavy hull the joint rows converge by
 // about 3 % per iteration (measured), a fixed point is not reached earlier.  Quantities that Box2D recomputes in every

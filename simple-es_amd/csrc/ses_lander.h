@@ -4,7 +4,7 @@
 //
 // The reference reaches this env through envs/gym_wrapper.py:9,36 (conf/lunarlander_openai.yaml, conf/lunarlander.yaml);
 // gym + Box2D are third-party and absent, so PARITY IS UNPINNED at this boundary: the two headers restate the published
-// algorithms and list what deviates (no continuous collision, own island order, float32 env arithmetic).
+// algorithms (continuous collision included) and list what deviates (own island order, float32 env arithmetic).
 //
 // This file supplies the B2_* macros of the device build and the small surface the rollout kernels use
 // (LanderState, ll_reset, ll_obs, ll_step).  The terrain of an episode (11 smoothed heights) lives in an LDS row owned
