@@ -302,12 +302,12 @@ __global__ __launch_bounds__(256) void k_es_apply(const float *__restrict__ part
     mu_out[p] = muv; m_out[p] = mv; v_out[p] = vv;
 }
 
-// ---- the openai_es fitness loop in four launches (ses_openai_generation) -----------------------------------------
+// ---- the openai_es fitness loop in three launches (ses_openai_generation) -----------------------------------------
 // Same arithmetic as k_rank_weights + k_es_grad_partial + k_es_apply + k_perturb, regrouped so that a generation needs
-// four small launches after the rollout instead of seven:
+// three small launches after the rollout instead of seven (five above 8192 rows: sort + search rank, separate update):
 //   * the rank-centring weight of a row is a closed form of its rank: formed where it is used (stage 1 of the gradient)
 //     instead of being written and re-read; the thread that meets rank 0 also reports best = max(fitness);
-//   * Adam's update of (mu, m, v) -- P parameters -- is done by the gradient kernel's last workgroup (chunk partials
+//   * Adam's update of (mu, m, v) -- P parameters -- is done by the gradient kernel's finishing workgroups (chunk partials
 //     added in the same ascending order), so no launch exists for it; old and new vectors are distinct buffers (the
 //     caller ping-pongs).  (An earlier form recomputed the update in every thread of the perturbation kernel: that
 //     kernel then took as long as the two it replaced, and O(n x chunks) reads made it 1 ms at 65 536 offspring.)
