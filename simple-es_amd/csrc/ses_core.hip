@@ -122,6 +122,7 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     h->tune_rollout_waves8 = 1024;
     h->tune_lander_per_wave = 0;
     h->tune_box2d_lpe = 0;
+    h->tune_es_final_max_chunks = 0;          // measured: the wave-per-parameter update launch beats the in-kernel finisher
     *out = h;
     return SES_OK;
 }
@@ -141,7 +142,8 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"rollout_mix", &ses_handle::tune_rollout_mix, 0, 1},
                                  {"rollout_waves8", &ses_handle::tune_rollout_waves8, 1, 1 << 20},
                                  {"lander_offspring_per_wave", &ses_handle::tune_lander_per_wave, 0, 4},
-                                 {"box2d_lanes_per_env", &ses_handle::tune_box2d_lpe, 0, 8}};
+                                 {"box2d_lanes_per_env", &ses_handle::tune_box2d_lpe, 0, 8},
+                                 {"es_final_max_chunks", &ses_handle::tune_es_final_max_chunks, 0, 1 << 20}};
     for (const Knob &k : knobs) {
         if (std::strcmp(k.name, name) == 0) {
             SES_REQUIRE(value >= k.lo && value <= k.hi, "ses_set_tuning: %s = %d outside [%d, %d]", name, value, k.lo, k.hi);

@@ -285,16 +285,27 @@ __global__ __launch_bounds__(256) void k_es_grad_partial(const double *__restric
     if (threadIdx.x < 4) partial[(size_t)blockIdx.y * P4 + 4 * q + threadIdx.x] = red[threadIdx.x][0];
 }
 
-// (mu, m, v) may be updated in place (mu_out == mu ...) or into other buffers
+// (mu, m, v) may be updated in place (mu_out == mu ...) or into other buffers.
+// One wavefront per parameter: lane c fetches the partial of chunk c (all chunks in flight at once), then the wave adds
+// them in ascending chunk order through v_readlane -- the same sum, in the same order, as a thread walking the chunks,
+// without its chain of dependent L2 reads (32 chunks: 9.9 -> ~3 us).
 __global__ __launch_bounds__(256) void k_es_apply(const float *__restrict__ partial, int chunks, int P, int P4,
                                                   float update_factor, double adam_a, const float *mu, const float *m,
                                                   const float *v, float *mu_out, float *m_out, float *v_out,
                                                   float *__restrict__ grad_out)
 {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= P) return;
-    float sum = partial[p];
-    for (int c = 1; c < chunks; ++c) sum = sum + partial[(size_t)c * P4 + p];
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= P) return;                                                  // wave-uniform
+    float sum = 0.0f;
+    for (int base = 0; base < chunks; base += 64) {
+        const float mine = base + lane < chunks ? partial[(size_t)(base + lane) * P4 + p] : 0.0f;
+        const int cnt = chunks - base < 64 ? chunks - base : 64;
+        for (int c = 0; c < cnt; ++c) {
+            const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), c));
+            sum = (base + c == 0) ? x : sum + x;
+        }
+    }
+    if (lane != 0) return;
     const float g = sum * update_factor;  // offspring_strategies.py:414
     if (grad_out) grad_out[p] = g;
     float muv = mu[p], mv = m[p], vv = v[p];
@@ -302,15 +313,16 @@ __global__ __launch_bounds__(256) void k_es_apply(const float *__restrict__ part
     mu_out[p] = muv; m_out[p] = mv; v_out[p] = vv;
 }
 
-// ---- the openai_es fitness loop in three launches (ses_openai_generation) -----------------------------------------
+// ---- the openai_es fitness loop in four launches (ses_openai_generation) -----------------------------------------
 // Same arithmetic as k_rank_weights + k_es_grad_partial + k_es_apply + k_perturb, regrouped so that a generation needs
-// three small launches after the rollout instead of seven (five above 8192 rows: sort + search rank, separate update):
+// four small launches after the rollout instead of seven (six above 8192 rows: sort + search rank):
 //   * the rank-centring weight of a row is a closed form of its rank: formed where it is used (stage 1 of the gradient)
 //     instead of being written and re-read; the thread that meets rank 0 also reports best = max(fitness);
-//   * Adam's update of (mu, m, v) -- P parameters -- is done by the gradient kernel's finishing workgroups (chunk partials
-//     added in the same ascending order), so no launch exists for it; old and new vectors are distinct buffers (the
-//     caller ping-pongs).  (An earlier form recomputed the update in every thread of the perturbation kernel: that
-//     kernel then took as long as the two it replaced, and O(n x chunks) reads made it 1 ms at 65 536 offspring.)
+//   * Adam's update of (mu, m, v) -- P parameters -- is k_es_apply, one wavefront per parameter (chunk partials added in
+//     ascending order); old and new vectors are distinct buffers (the caller ping-pongs).  FINAL == true moves it into
+//     this kernel instead (tuning knob "es_final_max_chunks"; measured slower, kept as a tested variant).  (An earlier
+//     form recomputed the update in every thread of the perturbation kernel: that kernel then took as long as the two it
+//     replaced, and O(n x chunks) reads made it 1 ms at 65 536 offspring.)
 //   * the keys of the counting rank are formed inside the count from the fitness values, the rank vector is cleared for
 //     the next generation by the perturbation kernel: no key kernel, no memset.
 // final == true: of the `chunks` workgroups that share a parameter quad, the one that finishes last (a ticket from the
@@ -379,7 +391,6 @@ __global__ __launch_bounds__(256) void k_es_grad_partial_ranked(const int32_t *_
     mu_out[p] = muv; m_out[p] = mv; v_out[p] = vv;
 }
 
-constexpr int ES_FUSED_APPLY_MAX_CHUNKS = 8;   // populations up to 8192 rows take the three-launch form
 
 // k_perturb for the openai_es population shape: global row 0 = mu, every other row mu + sigma * eps
 __global__ __launch_bounds__(256) void k_perturb_openai(const float *__restrict__ mu, float sigma, uint64_t seed,
@@ -599,7 +610,7 @@ int ses_es_update_philox(ses_handle *h, const double *weights, int32_t n, int32_
     float *partial = (float *)((char *)h->red_scratch + key_bytes);
     hipLaunchKernelGGL(k_es_grad_partial, dim3(quads, chunks), dim3(256), 0, h->stream, weights, n, skip_row0, seed, gen,
                        P4, partial);
-    hipLaunchKernelGGL(k_es_apply, dim3(ceil_div(h->P, 256)), dim3(256), 0, h->stream, partial, chunks, h->P, P4,
+    hipLaunchKernelGGL(k_es_apply, dim3(ceil_div(h->P, 4)), dim3(256), 0, h->stream, partial, chunks, h->P, P4,
                        (float)uf, adam_a, mu, m, v, mu, m, v, grad_out);
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;
@@ -636,7 +647,8 @@ int ses_openai_generation(ses_handle *h, const float *fitness, int32_t n, uint64
     // Small populations whose update runs in the fused kernel: keys formed inside the count (one launch less); the rank
     // vector is zero on entry -- cleared by that fused kernel at the end of the previous call, by a memset the first time
     // (or whenever the scratch moved or the population size changed).
-    const bool fused_count = n <= RANK_SORT_MIN && chunks <= ES_FUSED_APPLY_MAX_CHUNKS;
+    const bool fused_count = n <= RANK_SORT_MIN;                       // keys formed inside the counting rank
+    const bool final_in_grad = chunks <= h->tune_es_final_max_chunks;  // Adam by the gradient kernel's finishing workgroups
     if (fused_count) {
         if (h->rank_zeroed != rank || h->rank_zeroed_n != n) {
             SES_HIP_TRY(hipMemsetAsync(rank, 0, sizeof(int32_t) * (size_t)n, h->stream));
@@ -659,9 +671,8 @@ int ses_openai_generation(ses_handle *h, const float *fitness, int32_t n, uint64
     double uf = lr / ((double)n * sigma);            // offspring_strategies.py:406-408
     uf *= -1.0;
     unsigned int *counter = (unsigned int *)((char *)partial + sizeof(float) * (size_t)chunks * P4);
-    if (fused_count) {
-        // small populations: the gradient kernel's last workgroup finishes the update, the next launch perturbs the new
-        // mu and clears the rank vector for the next generation
+    if (final_in_grad) {
+        // the gradient kernel's finishing workgroups apply the update; the next launch perturbs the new mu
         if (h->counter_armed != counter) {
             SES_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int) * (size_t)quads, h->stream));
             h->counter_armed = counter;
@@ -669,23 +680,20 @@ int ses_openai_generation(ses_handle *h, const float *fitness, int32_t n, uint64
         hipLaunchKernelGGL((k_es_grad_partial_ranked<true>), dim3(quads, chunks), dim3(256), 0, h->stream, rank, fitness, n, 1,
                            seed, gen, P4, partial, best, counter, chunks, h->P, (float)uf, adam_a, mu_in, m_in, v_in, mu_out,
                            m_out, v_out);
-        const long long threads = (long long)(n_rows > 0 ? n_rows : 1) * quads;
-        hipLaunchKernelGGL(k_perturb_openai, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, mu_out, next_sigma, seed,
-                           next_gen, (long long)first_row, n_rows, h->P, quads, theta_next, h->stamp, rank, n);
     } else {
-        // large populations: a separate small launch finishes the update (every perturbation thread re-adding `chunks`
-        // partials would cost O(n * chunks) L2 reads: 65 536 offspring, 1 ms)
+        // a separate small launch finishes the update
         hipLaunchKernelGGL((k_es_grad_partial_ranked<false>), dim3(quads, chunks), dim3(256), 0, h->stream, rank, fitness, n, 1,
                            seed, gen, P4, partial, best, counter, chunks, h->P, (float)uf, adam_a, mu_in, m_in, v_in, mu_out,
                            m_out, v_out);
-        hipLaunchKernelGGL(k_es_apply, dim3(ceil_div(h->P, 256)), dim3(256), 0, h->stream, partial, chunks, h->P, P4,
+        hipLaunchKernelGGL(k_es_apply, dim3(ceil_div(h->P, 4)), dim3(256), 0, h->stream, partial, chunks, h->P, P4,
                            (float)uf, adam_a, mu_in, m_in, v_in, mu_out, m_out, v_out, (float *)nullptr);
-        if (n_rows > 0) {
-            const long long threads = (long long)n_rows * quads;
-            hipLaunchKernelGGL(k_perturb_openai, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, mu_out, next_sigma,
-                               seed, next_gen, (long long)first_row, n_rows, h->P, quads, theta_next, h->stamp,
-                               (int32_t *)nullptr, 0);
-        }
+    }
+    // the next population from the new mu; with the counting rank it also clears the rank vector for the next generation
+    if (n_rows > 0 || fused_count) {
+        const long long threads = (long long)(n_rows > 0 ? n_rows : 1) * quads;
+        hipLaunchKernelGGL(k_perturb_openai, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, mu_out, next_sigma, seed,
+                           next_gen, (long long)first_row, n_rows, h->P, quads, theta_next, h->stamp,
+                           fused_count ? rank : (int32_t *)nullptr, fused_count ? n : 0);
     }
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;

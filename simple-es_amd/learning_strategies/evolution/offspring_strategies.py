@@ -338,7 +338,7 @@ class openai_es(_DeviceStrategy):
         self.learning_rate = learning_rate
         self.mu_model = None
         self.optimizer = None
-        self.fused = bool(fused)      # philox noise: the whole fitness loop through ses_openai_generation (three launches)
+        self.fused = bool(fused)      # philox noise: the whole fitness loop through ses_openai_generation (four launches)
         self._spare = None
 
     def _population_size(self):
@@ -381,7 +381,7 @@ class openai_es(_DeviceStrategy):
 
     def _evaluate_fused(self, fit):
         """The same generation through ses_openai_generation: rank shaping, gradient, Adam and the next population
-        in three launches; (mu, m, v) ping-pong between two buffer triples.  Bit-identical to the step-by-step path
+        in four launches; (mu, m, v) ping-pong between two buffer triples.  Bit-identical to the step-by-step path
         (tests/test_gpu_host_mirror.py::test_openai_fused_generation_equals_stepwise)."""
         opt = self.optimizer
         a = opt.next_step_scale()

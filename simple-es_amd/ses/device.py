@@ -342,7 +342,7 @@ class HipES:
 
     def openai_generation(self, fitness, seed, gen, lr, sigma, adam_a, state_in, state_out, next_sigma, next_gen,
                           first_row, n_rows, theta_next=None, best=None):
-        """ses_openai_generation: rank shaping + ES gradient + Adam + the next population in three launches (five above 8192 rows).
+        """ses_openai_generation: rank shaping + ES gradient + Adam + the next population in four launches (six above 8192 rows).
         state_in / state_out: (mu, m, v) triples of distinct float32[P] tensors.  Returns theta_next[n_rows, P]."""
         n = fitness.shape[0]
         self._chk(fitness, "fitness", torch.float32, (n,))

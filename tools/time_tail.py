@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.join(ROOT, "simple-es_amd"))
 from ses import HipES
 
 es = HipES("CartPole-v1", 4, 2, True, False, max_step=500, eval_ep_num=5)
+if len(sys.argv) > 1:
+    es.set_tuning("es_final_max_chunks", int(sys.argv[1]))      # 0: the update always in its own launch
 per = 4096
 for world in (1, 2, 4, 8, 16):
     n = per * world
