@@ -515,6 +515,38 @@ def run_rank(args):
             except Exception as exc:
                 result["cpu_baseline_error"] = repr(exc)
     if world > 1:
+        # ---- the exchange alone, both transports, every rank in step: 16 KB and 128 KB per rank ------------------------
+        try:
+            owner = getattr(job.loop.dev, "_comm_owner", None)
+            micro = {}
+            if owner is not None:
+                have_p2p, have_rccl = owner.comm_p2p_info()[0] == world, owner.comm_info()[1] == world
+                for label, floats in (("16KB", 4096), ("128KB", 32768)):
+                    shard_t = torch.full((floats,), float(rank), device=owner.device)
+                    out_t = owner.empty(world * floats)
+                    for name, on, force in (("p2p_store_us", have_p2p, 0), ("rccl_us", have_rccl, 1)):
+                        if not on:
+                            continue
+                        owner.set_tuning("comm_force_rccl", force)
+                        for _ in range(10):
+                            owner.allgather_fitness(shard_t, out=out_t)
+                        torch.cuda.synchronize(); dist.barrier()
+                        with torch.cuda.stream(owner.stream):
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            for _ in range(100):
+                                owner.allgather_fitness(shard_t, out=out_t)
+                            e1.record()
+                        e1.synchronize()
+                        t = torch.tensor([e0.elapsed_time(e1) * 10.0], device=owner.device)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                        ok = bool(torch.equal(out_t.view(world, floats)[:, 0].cpu(), torch.arange(world, dtype=torch.float32)))
+                        micro.setdefault(label, {})[name] = round(float(t.item()), 2)
+                        micro[label]["correct"] = micro[label].get("correct", True) and ok
+                    owner.set_tuning("comm_force_rccl", 0)
+            result["allgather_microbench"] = dict(micro, ranks=world, note="100 back-to-back ses_allgather_fitness per transport, max over ranks, us per exchange")
+        except Exception as exc:
+            result["allgather_microbench"] = {"error": repr(exc)}
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -323,7 +323,7 @@ int ses_allgather_fitness(ses_handle *h, const float *local, int32_t n_per_rank,
     using namespace ses;
     SES_REQUIRE(h && local && all, "ses_allgather_fitness: null argument");
     SES_REQUIRE(n_per_rank >= 1, "ses_allgather_fitness: n_per_rank must be >= 1");
-    if (h->p2p && h->p2p->attached && n_per_rank <= h->p2p->max_per_rank) {
+    if (h->p2p && h->p2p->attached && n_per_rank <= h->p2p->max_per_rank && !(h->tune_comm_force_rccl && h->comm)) {
         ses_p2p *p = h->p2p;
         if (*(volatile uint32_t *)p->err_host != 0u)
             return set_error(SES_ERR_COMM, "ses_allgather_fitness: an earlier peer-store exchange timed out waiting for rank mask 0x%x "

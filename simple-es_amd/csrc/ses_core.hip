@@ -143,7 +143,8 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"rollout_waves8", &ses_handle::tune_rollout_waves8, 1, 1 << 20},
                                  {"lander_offspring_per_wave", &ses_handle::tune_lander_per_wave, 0, 4},
                                  {"box2d_lanes_per_env", &ses_handle::tune_box2d_lpe, 0, 8},
-                                 {"es_final_max_chunks", &ses_handle::tune_es_final_max_chunks, 0, 1 << 20}};
+                                 {"es_final_max_chunks", &ses_handle::tune_es_final_max_chunks, 0, 1 << 20},
+                                 {"comm_force_rccl", &ses_handle::tune_comm_force_rccl, 0, 1}};
     for (const Knob &k : knobs) {
         if (std::strcmp(k.name, name) == 0) {
             SES_REQUIRE(value >= k.lo && value <= k.hi, "ses_set_tuning: %s = %d outside [%d, %d]", name, value, k.lo, k.hi);

@@ -36,6 +36,7 @@ struct ses_handle {
     int32_t *rank_zeroed;
     int rank_zeroed_n;
     unsigned int *counter_armed;   // the last-block ticket counter in red_scratch that is known to be zero
+    int tune_comm_force_rccl;      // 1: ses_allgather_fitness ignores an attached peer-store transport (A/B measurements)
     int tune_es_final_max_chunks;  // ses_openai_generation: up to this many 1024-row chunks the gradient kernel applies Adam itself
     int tune_box2d_lpe;            // lanes per env of the Box2D MLP rollout: 0 = by population size, 1 / 2 / 4 / 8
     int tune_lander_per_wave;      // offspring per wave of the lockstep lander rollout: 0 = by population size, 1 / 2 / 4

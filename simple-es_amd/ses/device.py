@@ -221,7 +221,7 @@ class HipES:
         Peer stores when that transport is attached and the shard fits its mailbox, RCCL otherwise."""
         world, cap, _ = self.comm_p2p_info()
         if world < 1 or local.shape[0] > cap:
-            _, world, _ = self.comm_info()
+            _, world, _ = self.comm_info()                  # (with "comm_force_rccl" both transports span the same ranks)
         if world < 1:
             raise SesError("allgather_fitness: the handle has no communicator (comm_init or comm_p2p_attach first)")
         n = local.shape[0]
