@@ -47,7 +47,8 @@ extern "C" {
 #define SES_ENV_NONE (-1)  /* no env: handle only serves policy-forward / strategy kernels */
 #define SES_ENV_CARTPOLE 0 /* CartPole-v1 via envs/gym_wrapper.py:7-54 (conf/cartpole.yaml) */
 #define SES_ENV_LUNARLANDER 1 /* LunarLanderContinuous-v2 via envs/gym_wrapper.py (conf/lunarlander_openai.yaml): gym's env     */
-                              /* restated on a Box2D-style world (csrc/ses_lander.h, ses_b2.h; parity with gym / Box2D is   */
+                              /* restated on a Box2D-style world (csrc/ses_lander.h, ses_b2.h + ses_b2_toi.h: discrete solver  */
+                              /* and time-of-impact sub-stepping against the terrain; parity with gym / Box2D is              */
                               /* UNPINNED, neither is in the reference tree); num_state 8, num_action 4, continuous;        */
                               /* pomdp zeroes obs 2,3,5 (LunarLanderPOMDP, gym_wrapper.py:57-66); init rows: 16 uniforms   */
 #define SES_ENV_SIMPLE_SPREAD 2 /* pettingzoo MPE simple_spread via envs/pettingzoo_wrapper.py:6-64 (conf/simplespread.yaml); */
