@@ -336,6 +336,8 @@ int ses_allgather_fitness(ses_handle *h, const float *local, int32_t n_per_rank,
             peers.data[r] = (float *)p->peer[r];
             peers.flags[r] = (uint32_t *)((char *)p->peer[r] + p->flag_offset);
         }
+        if (p->seq == 0xFFFFFFFFu)                                       // 2^32 exchanges (weeks): the sequence words would wrap onto their initial 0
+            return set_error(SES_ERR_COMM, "ses_allgather_fitness: peer-store sequence exhausted; detach and attach the transport again");
         p->seq += 1;
         const int vec4 = (n_per_rank % 4 == 0) && ((uintptr_t)local % 16 == 0) && ((uintptr_t)all % 16 == 0);
         hipLaunchKernelGGL(k_allgather_p2p, dim3(p->world, ceil_div(n_per_rank, P2P_SPLIT)), dim3(256), 0, h->stream, local,
