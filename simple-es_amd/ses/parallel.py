@@ -12,6 +12,10 @@ mailboxes inside a node, RCCL otherwise): `attach_comm(dev)` sets the transports
 control plane that carries the mailbox handles / rank 0's 128-byte RCCL id between the ranks.  The torch.distributed
 route further down is what is left when neither is available (CPU tensors, or SES_COMM_P2P=0 with backend "gloo").
 """
+import os
+import socket
+import sys
+
 import torch
 import torch.distributed as dist
 
@@ -36,7 +40,6 @@ def _attach_p2p(owner, rank, world, group):
     """Peer-store transport (ses_comm_p2p_*): every rank exports a mailbox, the handles travel over the control plane,
     every rank maps the others; then ONE exchange of a known pattern is checked on every rank.  All ranks must be on one
     node.  Any failure on any rank -> every rank detaches (collective decision)."""
-    import os, socket
     if os.environ.get("SES_COMM_P2P", "1") == "0" or not 2 <= world <= 16:
         return False
     hosts = [None] * world
@@ -47,7 +50,7 @@ def _attach_p2p(owner, rank, world, group):
             handle = owner.comm_p2p_export(rank, world, P2P_MAX_PER_RANK)
         except Exception as exc:
             ok = False
-            print(f"[ses] rank {rank}: peer-store mailbox not available ({exc})", file=__import__("sys").stderr, flush=True)
+            print(f"[ses] rank {rank}: peer-store mailbox not available ({exc})", file=sys.stderr, flush=True)
     handles = [None] * world
     dist.all_gather_object(handles, handle, group=group)
     ok = ok and all(h is not None for h in handles)
@@ -56,7 +59,7 @@ def _attach_p2p(owner, rank, world, group):
             owner.comm_p2p_attach(handles)
         except Exception as exc:
             ok = False
-            print(f"[ses] rank {rank}: peer mailboxes not mappable ({exc})", file=__import__("sys").stderr, flush=True)
+            print(f"[ses] rank {rank}: peer mailboxes not mappable ({exc})", file=sys.stderr, flush=True)
     ok = _cpu_group_ok(ok, owner.device, group)            # also: nobody starts the test before everybody has attached
     if ok:
         try:
@@ -68,7 +71,7 @@ def _attach_p2p(owner, rank, world, group):
             ok = bool(torch.equal(got, want))
         except Exception as exc:
             ok = False
-            print(f"[ses] rank {rank}: peer-store self-test failed ({exc})", file=__import__("sys").stderr, flush=True)
+            print(f"[ses] rank {rank}: peer-store self-test failed ({exc})", file=sys.stderr, flush=True)
         ok = _cpu_group_ok(ok, owner.device, group)
     if not ok:
         try:
