@@ -50,6 +50,7 @@ class ESLoop(BaseESLoop):
         self._prefetched = None     # ((generation, first row, rows), init states, event) drawn ahead on the side stream
         self._side = None
         self._side_dev = None
+        self._main = None                       # the launch stream, looked up once
 
         # logs/<env>/<timestamp>[_k]: the reference's makedirs (loop.py:40-47) raises when two loops start in the same
         # second; here the second one gets a suffix instead of silently sharing the directory.  Only rank 0 writes.
@@ -93,8 +94,10 @@ class ESLoop(BaseESLoop):
         # drawn on a side stream while rollout g runs (a 4 us kernel that would otherwise sit between the last kernel of
         # one generation and the rollout of the next); the launch stream waits for the side stream's event, long done.
         pre = self._prefetched
+        if self._main is None:
+            self._main = torch.cuda.current_stream(self.dev.device)           # the loop's launch stream, looked up once (8 us a call)
         if pre is not None and pre[0] == (population.gen, shard.first, shard.n_local):
-            torch.cuda.current_stream().wait_event(pre[2])
+            self._main.wait_event(pre[2])
             init = pre[1]
         else:
             init = self._init_states(population.gen, shard)
@@ -114,7 +117,7 @@ class ESLoop(BaseESLoop):
                 if shard.n_local != nxt.shape[0]:
                     nxt = nxt[: shard.n_local].contiguous()
             done.record()
-        nxt.record_stream(torch.cuda.current_stream())                        # consumed by the next rollout on the launch stream
+        nxt.record_stream(self._main)                                         # consumed by the next rollout on the launch stream
         self._prefetched = ((population.gen + 1, shard.first, shard.n_local), nxt, done)
         return shard.allgather_fitness(local, dev=self.dev)
 

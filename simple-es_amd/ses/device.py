@@ -267,10 +267,11 @@ class HipES:
                                                int(n_rows), _ptr(theta), _ptr(store)), "ses_perturb_host_noise")
         return (theta, store) if want_eps_store else theta
 
-    def init_states_uniform(self, seed, gen, first_row, n_rows, shared=False, lo=None, hi=None):
+    def init_states_uniform(self, seed, gen, first_row, n_rows, shared=False, lo=None, hi=None, out=None):
         lo = self.init_range[0] if lo is None else lo
         hi = self.init_range[1] if hi is None else hi
-        out = self.empty(n_rows, self.E, self.init_dim)
+        out = (self.empty(n_rows, self.E, self.init_dim) if out is None else
+               self._chk(out, "out", torch.float32, (n_rows, self.E, self.init_dim)))
         check(self._lib.ses_init_states_uniform(self._h, int(seed), int(gen), int(first_row), int(n_rows),
                                                 int(bool(shared)), int(self.init_dim), float(lo), float(hi), _ptr(out)),
               "ses_init_states_uniform")
