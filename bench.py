@@ -429,7 +429,24 @@ def run_rank(args):
             result["rollout_kernel"].update({"bound": "fp32 mfma + valu (serial)", "mfma_tflops": flops / (roll_ms * 1e-3) / 1e12,
                                              "mfma_peak_tflops": 157.3,
                                              "mfma_frac": flops / (roll_ms * 1e-3) / 157.3e12,
-                                             "mfma": "v_mfma_f32_16x16x4_f32; MfmaUtil 56 % in profiles/r01_sq_gru_mfma.txt"})
+                                             "mfma": "v_mfma_f32_16x16x4_f32"})
+            # matrix-pipe busy fraction (rocprof's MfmaUtil) from the newest committed SQ profile of this kernel, attached
+            # only while the kernel's machine code is the profiled one
+            newest = None
+            for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+                if name.endswith("_sq_gru_mfma.json"):
+                    newest = os.path.join(ROOT, "profiles", name)
+            if newest:
+                sqm = json.load(open(newest))
+                now = kernel_code_hash("k_rollout_gru_mfma")
+                pd_ = sqm.get("per_dispatch", {})
+                if sqm.get("kernel_code_sha256") and now == sqm["kernel_code_sha256"] and pd_.get("GRBM_GUI_ACTIVE"):
+                    # GRBM_GUI_ACTIVE is summed over the 8 XCDs, each with 128 SIMDs
+                    result["rollout_kernel"]["mfma_util"] = pd_["SQ_VALU_MFMA_BUSY_CYCLES"] / (pd_["GRBM_GUI_ACTIVE"] * 128.0)
+                    result["rollout_kernel"]["mfma_util_source"] = os.path.relpath(newest, ROOT)
+                else:
+                    result["rollout_kernel"]["mfma_util_note"] = (f"{os.path.relpath(newest, ROOT)} was collected on different "
+                                                                  "machine code of this kernel: not attached")
         # VALU issue roofline of the rollout kernel: instruction count from the newest committed SQ counter profile of
         # this same workload (attached only while the kernel's machine code is the profiled one), duration live
         suffix, frag = ("_sq_gru_lockstep.json", "k_rollout_gru_lockstep") if args.gru else ("_sq_rollout.json", "k_rollout_cartpole_mlp")
