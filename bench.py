@@ -13,7 +13,7 @@ synthetic fixed-length episodes of 500 steps (termination masked: every counted 
 forward + physics step).  One "step" = one generation of the PRODUCT loop: `ESLoop.generation()` of
 simple-es_amd/learning_strategies/evolution/loop.py driven by the `openai_es` strategy object -- the same
 method `ESLoop.run()` (and therefore `run_es.py`) loops over, everything on device:
-    env resets (Philox) -> fused rollout kernel -> fitness all-gather (RCCL, N > 1) -> rank-centring ->
+    env resets (Philox) -> fused rollout kernel -> fitness all-gather (peer stores or RCCL, N > 1) -> rank-centring ->
     ES gradient + Adam -> Philox perturbation of the next population (member 0 = mu).
 Parameters, Adam moments and the population are resident in HBM before the timed region.
 
@@ -21,13 +21,18 @@ Three population sizes are measured per run (`value` is the first):
     weak      4096 offspring PER GPU   (per-GPU work fixed: "scaling": "weak")
     strong    4096 offspring in total  (the literal reading of BASELINE.json's metric)
     c4        65 536 offspring in total (BASELINE.json configs[3])
-each with the RCCL rank count, the all-gather time and the per-rank fitness-loop time.
+each with the transport of the all-gather, its time and the per-rank fitness-loop time; at N > 1 also
+`allgather_microbench` (the exchange alone over each transport).
 
 Extra legs (rank 0): `roofline` -- the standalone SoA env-step kernel at 2^24 envs against the HBM roof
 (SURVEY 8d: 52 algorithmic bytes per env-step), timed with HIP events on the launch stream;
 `loop_ms_per_generation` -- ESLoop.run() itself, prints and metrics included;
 `cpu_baseline` -- the reference-structured Python multiprocessing port on the host cores (N = 1 only).
 """
+import os
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: both multi-GPU transports need it; before any HIP call
+
 import argparse
 import contextlib
 import hashlib
