@@ -7,6 +7,8 @@ import argparse
 import os
 import random
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC for the multi-GPU transports; before any HIP call
+
 import numpy as np
 import torch
 import yaml
