@@ -90,7 +90,7 @@ int ses_sync(ses_handle *h);
  * same canonical arithmetic, so no setting changes a result; the defaults are the measured crossovers.  Knobs:
  * "gru_ep_parallel_max" (default 4096), "gru_mfma_min_e" (12), "gru_sequential" (0), "rollout_mix" (1),
  * "rollout_waves8" (1024), "rollout_block" (64 | 256), "lander_offspring_per_wave" (0 = by population size | 1 | 2 | 4),
- * "box2d_lanes_per_env" (0 = by population size | 1 | 2 | 4 | 8: lanes that share one env in the LunarLander / BipedalWalker MLP rollout),
+ * "box2d_lanes_per_env" (0 = by population size | 1 | 2 | ... | 64: lanes that share one env in the LunarLander / BipedalWalker MLP rollout),
  * "es_final_max_chunks" (0: ses_openai_generation applies Adam in its own small launch; k > 0: inside the gradient kernel for
  * populations of up to k * 1024 rows), "comm_force_rccl" (1: ses_allgather_fitness uses the RCCL communicator although the
  * peer-store transport is attached -- for measuring one against the other).

@@ -142,7 +142,7 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"rollout_mix", &ses_handle::tune_rollout_mix, 0, 1},
                                  {"rollout_waves8", &ses_handle::tune_rollout_waves8, 1, 1 << 20},
                                  {"lander_offspring_per_wave", &ses_handle::tune_lander_per_wave, 0, 4},
-                                 {"box2d_lanes_per_env", &ses_handle::tune_box2d_lpe, 0, 8},
+                                 {"box2d_lanes_per_env", &ses_handle::tune_box2d_lpe, 0, 64},
                                  {"es_final_max_chunks", &ses_handle::tune_es_final_max_chunks, 0, 1 << 20},
                                  {"comm_force_rccl", &ses_handle::tune_comm_force_rccl, 0, 1}};
     for (const Knob &k : knobs) {
@@ -153,7 +153,7 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
             SES_REQUIRE(k.field != &ses_handle::tune_lander_per_wave || value != 3,
                         "ses_set_tuning: lander_offspring_per_wave must be 0, 1, 2 or 4");
             SES_REQUIRE(k.field != &ses_handle::tune_box2d_lpe || (value & (value - 1)) == 0,
-                        "ses_set_tuning: box2d_lanes_per_env must be 0, 1, 2, 4 or 8");
+                        "ses_set_tuning: box2d_lanes_per_env must be 0 or a power of two up to 64");
             h->*(k.field) = value;
             return SES_OK;
         }

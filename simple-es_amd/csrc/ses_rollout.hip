@@ -706,9 +706,11 @@ __global__ __launch_bounds__(256, 2) void k_rollout_lander_gru(const float *__re
 }
 
 // MLP policies on the Box2D-style envs (LunarLander: conf/lunarlander.yaml, BipedalWalker: conf/bipedalwalker.yaml):
-// LPE lanes per env (32 / LPE hidden units each) for the forward, every lane of a group carries the env.  The world
+// LPE lanes per env (LPE <= 8: 32 / LPE hidden units each for the forward; above: the whole forward in every lane), every
+// lane of a group carries the env.  The world
 // step is ~20 000 instructions whatever the number of lanes that carry an env, so LPE only decides how many waves the
-// population makes: box2d_lanes_per_env() picks the largest LPE that keeps it at about one wave per SIMD.
+// population makes: box2d_lanes_per_env() picks the largest LPE (up to 64: one env per wave) that keeps it within one
+// wave per SIMD -- the fewer envs share a wave, the less each pays for the others' contacts and impacts.
 // Single-wave workgroups (they spread over all SIMDs and retire independently).  EnvB adapts an env.
 struct LanderMlpEnv {
     static constexpr int S = 8, A = 4, INIT_W = 16, ROW = LL_TERRAIN_ROW;
@@ -765,7 +767,12 @@ __global__ __launch_bounds__(64, EnvB::WAVES_PER_SIMD) void k_rollout_box2d_mlp(
         EnvB::observe(st, obs);
 #pragma unroll
         for (int k = 0; k < S; ++k) obs[k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
-        if constexpr (LPE >= 4) {
+        if constexpr (LPE > 8) {
+            // 16, 32 or 64 lanes per env: small populations, where an env that has a wave (or a good part of one) to itself
+            // pays for its own contacts, impacts and position iterations only, not for the union over its wave-mates';
+            // every lane evaluates the whole (tiny) policy, no cross-lane step
+            mlp_forward_streamed<S, A, 1>(theta + (size_t)row * P, 0, tanh_tab, obs, logits);
+        } else if constexpr (LPE >= 4) {
             MlpSlice<S, A, LPE> net;
             net.load(theta + (size_t)row * P, sub);
             net.forward(tanh_tab, obs, logits);
@@ -1023,7 +1030,7 @@ static void launch_rollout(const ses_handle *h, const float *theta, const float 
 static int box2d_lanes_per_env(const ses_handle *h, long long episodes)
 {
     if (h->tune_box2d_lpe) return h->tune_box2d_lpe;
-    int lpe = 8;
+    int lpe = 64;
     while (lpe > 1 && episodes * lpe > 64ll * 1024) lpe >>= 1;
     return lpe;
 }
@@ -1038,7 +1045,10 @@ static void launch_box2d_mlp(ses_handle *h, const float *theta, const float *ini
 #define SES_BOX2D_LAUNCH(L)                                                                                          \
     hipLaunchKernelGGL((k_rollout_box2d_mlp<EnvB, L>), grid, block, 0, h->stream, theta, init, per, n_rows,           \
                        h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, epr, ep_steps)
-    if (lpe == 8) SES_BOX2D_LAUNCH(8);
+    if (lpe == 64) SES_BOX2D_LAUNCH(64);
+    else if (lpe == 32) SES_BOX2D_LAUNCH(32);
+    else if (lpe == 16) SES_BOX2D_LAUNCH(16);
+    else if (lpe == 8) SES_BOX2D_LAUNCH(8);
     else if (lpe == 4) SES_BOX2D_LAUNCH(4);
     else if (lpe == 2) SES_BOX2D_LAUNCH(2);
     else SES_BOX2D_LAUNCH(1);

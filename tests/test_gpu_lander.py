@@ -36,7 +36,7 @@ def test_lander_gru_golden_and_oracle(golden_dir):
 
 
 @pytest.mark.parametrize("gru,pomdp,lpe", [(True, False, 0), (False, True, 0), (False, False, 0), (False, False, 4),
-                                           (False, True, 2), (False, False, 1)])
+                                           (False, True, 2), (False, False, 1), (False, False, 8), (False, True, 16), (False, False, 64)])
 def test_lander_population_bit_exact(gru, pomdp, lpe):
     """lpe: lanes per env of the MLP rollout kernel (0 = the library's choice, 8 at this size)."""
     from ses import HipES

@@ -20,7 +20,7 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("n,E,T,lpe", [(1, 1, 40, 0), (37, 3, 150, 0), (37, 3, 150, 4), (37, 3, 150, 2), (37, 3, 150, 1)])
+@pytest.mark.parametrize("n,E,T,lpe", [(1, 1, 40, 0), (37, 3, 150, 0), (37, 3, 150, 8), (37, 3, 150, 4), (37, 3, 150, 2), (37, 3, 150, 1), (37, 3, 150, 32)])
 def test_walker_population_bit_exact(n, E, T, lpe):
     """lpe: lanes per env of the rollout kernel (0 = the library's choice, 8 at this size); 1 and 2 stream the weights."""
     from ses import HipES

@@ -65,7 +65,7 @@ def main():
             n, E, T = int(rng.choice([1, 6, 40])), int(rng.choice([1, 3, 5, 9, 13])), int(rng.choice([5, 60, 150]))
             pomdp = bool(rng.randint(0, 2))
             es = HipES("LunarLanderContinuous-v2", 8, 4, False, gru, pomdp=pomdp, max_step=T, eval_ep_num=E)
-            es.set_tuning("box2d_lanes_per_env", int(rng.choice([0, 1, 2, 4, 8])))     # MLP kernel only
+            es.set_tuning("box2d_lanes_per_env", int(rng.choice([0, 1, 2, 4, 8, 16, 64])))     # MLP kernel only
             theta = (rng.randn(n, es.P) * min(sigma, 1.0)).astype(np.float32)
             init = rng.uniform(0, 1, (E, 16) if shared else (n, E, 16)).astype(np.float32)
             ref = co.rollout_lander(theta, init, E, T, gru=gru, obs_mask=0b101100 if pomdp else 0)
@@ -75,7 +75,7 @@ def main():
         elif kind == "walker":
             n, E, T = int(rng.choice([1, 5, 33])), int(rng.choice([1, 2, 5])), int(rng.choice([5, 60, 150]))
             es = HipES("BipedalWalker-v3", 24, 4, False, False, max_step=T, eval_ep_num=E)
-            es.set_tuning("box2d_lanes_per_env", int(rng.choice([0, 1, 2, 4, 8])))
+            es.set_tuning("box2d_lanes_per_env", int(rng.choice([0, 1, 2, 4, 8, 16, 64])))
             theta = (rng.randn(n, es.P) * sigma).astype(np.float32)
             init = rng.uniform(0, 1, (E, 4) if shared else (n, E, 4)).astype(np.float32)
             ref = co.rollout_walker(theta, init, E, T)
