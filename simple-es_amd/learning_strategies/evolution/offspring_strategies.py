@@ -294,13 +294,17 @@ class simple_evolution(_DeviceStrategy):
         return self.offspring_num + 1
 
     def _gen_offsprings(self, agent_ids, elite_models, mu_model, sigma, offspring_num):
-        parents = torch.stack([mu_model, elite_models]).contiguous()
+        # after evaluate() the elite IS the mean (the reference's in-place sum, offspring_strategies.py:234-248), and at
+        # the start both are the zero network: one parent row then serves slots 0 and 1 -- no torch.stack (20 us of host
+        # time and a copy kernel per generation, a tenth of a 96-offspring generation)
+        same = elite_models is mu_model or elite_models.data_ptr() == mu_model.data_ptr()
+        parents = mu_model.view(1, -1) if same else torch.stack([mu_model, elite_models]).contiguous()
 
         def build():
             idx = np.zeros(offspring_num + 1, dtype=np.int32)
-            idx[0], idx[1] = -1, -2               # [mu, elite0, then N-1 children of mu]
+            idx[0], idx[1] = -1, (-1 if same else -2)    # [mu, elite0, then N-1 children of mu]
             return idx
-        return self._materialise(parents, self._const_map(("evolution", offspring_num), build), sigma)
+        return self._materialise(parents, self._const_map(("evolution", offspring_num, same), build), sigma)
 
     def get_elite_model(self):
         return self._model_from(self.elite0)
