@@ -1,7 +1,7 @@
 """python run_es.py --cfg-path conf/cartpole.yaml  -- same flags as the reference CLI (run_es.py:15-62).
 
 Multi-GPU: launch one rank per GPU with torch.distributed.run; the population is sharded over the ranks
-and the fitness vector is all-gathered over RCCL.
+and the fitness vector is all-gathered inside the library (peer stores over xGMI, RCCL as the second transport).
 """
 import argparse
 import os
