@@ -113,8 +113,16 @@ def spawn(args):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def env_step_roofline(es, n_env, launches=20):
-    """Average duration of k_env_step_cartpole over `launches` launches, HIP events on the launch stream."""
+def env_step_roofline(es, n_env, launches=20, batches=15, preroll=200):
+    """Duration of k_env_step_cartpole_v4 at n_env envs, HIP events on the launch stream (torch's current stream IS the
+    handle's stream).  Protocol: 3 launches to touch every page, then the FIRST batch of `launches`
+    back-to-back launches is timed and reported separately (`first_batch_us`: the box as the bench finds it), then
+    `preroll` untimed launches, then `batches` timed batches; `avg_launch_us` / `achieved` / `frac` are the MEDIAN of those
+    batches (a batch between two events never lets the queue drain, so the quotient is the kernel's own duration --
+    cross-checked against rocprofv3 --kernel-trace in profiles/).  Next to it, measured the same way in the same
+    process: `copy13` = ses_stream_probe, the same 13 streams over the same arrays with no arithmetic (hand-written
+    float4 non-temporal copy: the ceiling of this access pattern on this box), and torch's device-to-device copy of the
+    same byte count (two streams)."""
     from ses import MODE_FIXED_LENGTH
     g = torch.Generator(device="cuda").manual_seed(0)
     x, xd, th, thd, action, ret, status = es.alloc_env_soa(n_env)
@@ -122,41 +130,53 @@ def env_step_roofline(es, n_env, launches=20):
         t.copy_((torch.rand(n_env, device="cuda", generator=g) - 0.5) * 0.1)
     action.copy_((torch.rand(n_env, device="cuda", generator=g) > 0.5).to(torch.int32))
     st = [x, xd, th, thd]
-    for _ in range(3):
+
+    def step():
         es.env_step(*st, action, ret, status, mode=MODE_FIXED_LENGTH)
-    torch.cuda.synchronize()
-    # `launches` back-to-back launches between two HIP events on the launch stream (torch's current stream
-    # IS the handle's stream): the queue never drains, so the quotient is the kernel's own duration
-    # (cross-checked against rocprofv3 --kernel-trace in profiles/).
-    batches = []
-    for _ in range(7):                                         # median batch: a transient slow batch (~8 %) shows up
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # about once in ten
+
+    def probe():
+        es.stream_probe(*st, action, ret, status)
+
+    def batch(fn, k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(launches):
-            es.env_step(*st, action, ret, status, mode=MODE_FIXED_LENGTH)
+        for _ in range(k):
+            fn()
         e1.record()
         e1.synchronize()
-        batches.append(e0.elapsed_time(e1) * 1e-3 / launches)
-    avg = sorted(batches)[len(batches) // 2]
+        return e0.elapsed_time(e1) * 1e-3 / k
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    first = batch(step, launches)
+    for _ in range(preroll):
+        step()
+    torch.cuda.synchronize()
+    # env-step and probe batches alternate, so that drift of the box (clocks, memory temperature) is common to both
+    steps, probes = [], []
+    for _ in range(batches):
+        steps.append(batch(step, launches))
+        probes.append(batch(probe, launches))
+    avg = statistics.median(steps)
+    probe_avg = statistics.median(probes)
     achieved = BYTES_PER_ENV_STEP * n_env / avg / 1e9
-    # this box's streaming ceiling for the same byte count: a plain device-to-device copy (read half, write half)
+    copy13 = BYTES_PER_ENV_STEP * n_env / probe_avg / 1e9
+    # torch's device-to-device copy of the same byte count (read half, write half: two streams)
     half = BYTES_PER_ENV_STEP * n_env // 2
     src, dst = torch.empty(half, dtype=torch.uint8, device="cuda"), torch.empty(half, dtype=torch.uint8, device="cuda")
     dst.copy_(src)
-    copies = []
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            dst.copy_(src)
-        e1.record()
-        e1.synchronize()
-        copies.append(e0.elapsed_time(e1) * 1e-3 / 10)
-    copy_gbs = 2 * half / sorted(copies)[len(copies) // 2] / 1e9
+    copies = [batch(lambda: dst.copy_(src), 10) for _ in range(5)]
+    copy_gbs = 2 * half / statistics.median(copies) / 1e9
     del src, dst
     return {"bound": "hbm", "kernel": "k_env_step_cartpole_v4", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "n_env": n_env, "avg_launch_us": avg * 1e6, "batch_avg_us": [round(b * 1e6, 2) for b in batches],
+            "n_env": n_env, "avg_launch_us": avg * 1e6, "batch_avg_us": [round(b * 1e6, 2) for b in steps],
+            "batches": batches, "launches_per_batch": launches, "preroll_launches": preroll,
+            "first_batch_us": first * 1e6, "first_batch_frac": BYTES_PER_ENV_STEP * n_env / first / 1e9 / HBM_PEAK_GBS,
+            "best_batch_us": min(steps) * 1e6,
+            "copy13_us": probe_avg * 1e6, "copy13_gbs": copy13, "frac_of_copy13": achieved / copy13,
+            "copy13": "ses_stream_probe: the same 7 load + 6 store streams, float4 non-temporal, no arithmetic, same grid",
             "copy_same_bytes_gbs": copy_gbs, "frac_of_copy": achieved / copy_gbs,
             "env_steps_per_s": n_env / avg,
             "bytes_per_env_step": BYTES_PER_ENV_STEP}
@@ -541,8 +561,11 @@ def run_rank(args):
         try:
             owner = getattr(job.loop.dev, "_comm_owner", None)
             micro = {}
+            have_p2p = owner is not None and owner.comm_route()[0] == world
+            have_rccl = owner is not None and owner.comm_route()[2] == world
+            for label, floats in (("16KB", 4096), ("128KB", 32768)):
+                micro[label] = {"p2p_store_us": "absent", "rccl_us": "absent"}     # a transport that could not be set up says so
             if owner is not None:
-                have_p2p, have_rccl = owner.comm_p2p_info()[0] == world, owner.comm_info()[1] == world
                 for label, floats in (("16KB", 4096), ("128KB", 32768)):
                     shard_t = torch.full((floats,), float(rank), device=owner.device)
                     out_t = owner.empty(world * floats)
@@ -563,10 +586,12 @@ def run_rank(args):
                         t = torch.tensor([e0.elapsed_time(e1) * 10.0], device=owner.device)
                         dist.all_reduce(t, op=dist.ReduceOp.MAX)
                         ok = bool(torch.equal(out_t.view(world, floats)[:, 0].cpu(), torch.arange(world, dtype=torch.float32)))
-                        micro.setdefault(label, {})[name] = round(float(t.item()), 2)
+                        micro[label][name] = round(float(t.item()), 2)
                         micro[label]["correct"] = micro[label].get("correct", True) and ok
                     owner.set_tuning("comm_force_rccl", 0)
-            result["allgather_microbench"] = dict(micro, ranks=world, note="100 back-to-back ses_allgather_fitness per transport, max over ranks, us per exchange")
+            result["allgather_microbench"] = dict(micro, ranks=world, transports={"p2p_store": "attached" if have_p2p else "absent",
+                                                                                    "rccl": "attached" if have_rccl else "absent"},
+                                                  note="100 back-to-back ses_allgather_fitness per transport, max over ranks, us per exchange")
         except Exception as exc:
             result["allgather_microbench"] = {"error": repr(exc)}
         dist.barrier()

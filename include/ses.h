@@ -93,7 +93,9 @@ int ses_sync(ses_handle *h);
  * "box2d_lanes_per_env" (0 = by population size | 1 | 2 | ... | 64: lanes that share one env in the LunarLander / BipedalWalker MLP rollout),
  * "es_final_max_chunks" (0: ses_openai_generation applies Adam in its own small launch; k > 0: inside the gradient kernel for
  * populations of up to k * 1024 rows), "comm_force_rccl" (1: ses_allgather_fitness uses the RCCL communicator although the
- * peer-store transport is attached -- for measuring one against the other).
+ * peer-store transport is attached -- for measuring one against the other), "comm_p2p_timeout_ms" (how long a peer-store
+ * exchange waits for a peer's shard; 0 = default 60000), "comm_p2p_keep_going" (1: after a time-out later exchanges still
+ * run instead of failing; the host polls ses_comm_p2p_status, agrees with the other ranks and rolls back -- ESLoop.run()).
  * The library itself reads no environment variable. */
 int ses_set_tuning(ses_handle *h, const char *name, int32_t value);
 /* Timing without events: from now on the last kernel of every ses_rollout (the episode mean: end of the rollout phase)
@@ -158,6 +160,14 @@ int ses_policy_forward(ses_handle *h, const float *theta, const float *obs, floa
  * at |x| > 2.4 or |th| > 0.2095), which matter in SES_MODE_FIXED_LENGTH where finished envs keep stepping. */
 int ses_env_step(ses_handle *h, int32_t n, int32_t mode, float *x, float *xd, float *th, float *thd,
                  const int32_t *action, float *ret, uint32_t *status);
+
+/* Measurement aid for the roofline of ses_env_step (no reference counterpart): the same 13 streams -- 7 x 16-byte
+ * non-temporal loads and 6 x 16-byte non-temporal stores per lane over the same arrays, same grid -- with no arithmetic
+ * in between; every value is written back unchanged.  Its duration is what the memory system of the box gives this
+ * access pattern; bench.py prints it next to the env-step kernel's (roofline.copy13_*).  n a multiple of 4, arrays
+ * 16-byte aligned. */
+int ses_stream_probe(ses_handle *h, int32_t n, float *x, float *xd, float *th, float *thd, const int32_t *action,
+                     float *ret, uint32_t *status);
 
 /* ---- fused rollout: RolloutWorker for the whole shard (loop.py:108-125) -------------------- */
 /*
@@ -258,8 +268,11 @@ int ses_allgather_fitness(ses_handle *h, const float *local, int32_t n_per_rank,
  * memory, the W - 1 peers map it (hipIpc*), and one small kernel per rank stores its shard into every peer's mailbox,
  * publishes a sequence number and collects the peers' shards from its own mailbox -- the latency of one xGMI store
  * instead of W - 1 ring hops behind a library launch.  Once attached, ses_allgather_fitness uses it for n_per_rank <=
- * max_per_rank (results identical: it is a copy).  A wait that exceeds 2 s NaN-fills the missing shard and makes the
- * next ses_allgather_fitness fail with SES_ERR_COMM; after ses_comm_p2p_detach the handle is back on RCCL.
+ * max_per_rank (results identical: it is a copy).  A wait that exceeds the time-out ("comm_p2p_timeout_ms", default 60 s)
+ * NaN-fills the missing shard and sets that peer's bit in a host-visible word: ses_comm_p2p_status reads it at any time
+ * without touching the stream (once the kernels that consume an exchange have finished, the word is final for it -- check
+ * it before a generation's results are used or checkpointed), and the next ses_allgather_fitness fails with SES_ERR_COMM
+ * unless "comm_p2p_keep_going" is set; after ses_comm_p2p_detach the handle is back on RCCL.
  *   ses_comm_p2p_export : allocate this rank's mailbox; handle[SES_COMM_P2P_HANDLE_BYTES] is what the peers need.
  *   ses_comm_p2p_attach : handles = the W exported handles in rank order (W * SES_COMM_P2P_HANDLE_BYTES bytes, gathered
  *                         by the host's control plane); maps the peers.  Every rank must have exported before any attaches.
@@ -270,6 +283,7 @@ int ses_allgather_fitness(ses_handle *h, const float *local, int32_t n_per_rank,
 int ses_comm_p2p_export(ses_handle *h, int32_t rank, int32_t world, int32_t max_per_rank, void *handle);
 int ses_comm_p2p_attach(ses_handle *h, const void *handles);
 int ses_comm_p2p_info(ses_handle *h, int32_t *world, int32_t *max_per_rank, int32_t *exchanges);
+int ses_comm_p2p_status(ses_handle *h, uint32_t *timed_out_mask);   /* bit r: an exchange gave up waiting for rank r */
 int ses_comm_p2p_detach(ses_handle *h);
 
 #ifdef __cplusplus

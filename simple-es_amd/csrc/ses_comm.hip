@@ -16,9 +16,14 @@
 // peer b's shard out -- one store, one flag, no hops, no intermediate rank.  Two slots alternate by sequence parity:
 // a peer can only be one exchange ahead (its next exchange needs this rank's next flag, which is stream-ordered after
 // this rank's reads), so slot (seq & 1) is never overwritten while it is still being read.
-// A wait gives up after P2P_TIMEOUT_TICKS of the 100 MHz real-time counter: the shard is filled with NaN and a
-// host-visible error word is set, which the next ses_allgather_fitness reports (SES_ERR_COMM) -- no kernel of this
-// library spins for ever.
+// A wait gives up after the handle's time-out (ses_set_tuning "comm_p2p_timeout_ms", default 60 s -- RCCL would wait for
+// ever; a stalled rank is usually a checkpoint write or a page-in, not a dead peer) of the 100 MHz real-time counter: the
+// shard is filled with NaN and a bit is set in a host-visible error word (ses_comm_p2p_status reads it without touching
+// the stream) -- no kernel of this library spins for ever.  A sequence word that is already PAST the awaited exchange
+// (the peer gave up on this rank earlier and moved on) is an error at once, without waiting.  By default the next
+// ses_allgather_fitness then fails with SES_ERR_COMM; with "comm_p2p_keep_going" = 1 later exchanges still run (every
+// rank keeps publishing, so nobody waits a time-out per generation) and the HOST is expected to poll the status word,
+// agree with the other ranks and roll back -- ESLoop.run() does exactly that at its checkpoint boundaries.
 #include <dlfcn.h>
 
 #include <cstring>
@@ -47,7 +52,7 @@ static Rccl g_rccl;
 
 // ---- peer-store transport ---------------------------------------------------------------------------------------
 constexpr int P2P_MAX_WORLD = 16;
-constexpr unsigned long long P2P_TIMEOUT_TICKS = 200000000ull;   // 2 s of the 100 MHz counter
+constexpr unsigned long long P2P_TICKS_PER_MS = 100000ull;       // the real-time counter runs at 100 MHz
 
 }  // namespace ses
 
@@ -60,6 +65,7 @@ struct ses_p2p {
     uint32_t seq;                           // exchanges issued so far
     uint32_t *err_host;                     // pinned host word set by a kernel that timed out
     uint32_t *err_dev;                      // its device alias
+    unsigned long long timeout_ticks;       // how long a workgroup waits for a peer's sequence word
 };
 
 namespace ses {
@@ -77,7 +83,8 @@ constexpr int P2P_SPLIT = 4096;          // floats one workgroup moves; a shard 
 // its own grid.  16-byte accesses when n and the pointers allow (the mailbox is uncached memory: wide and few).
 __global__ __launch_bounds__(256) void k_allgather_p2p(const float *__restrict__ local, int n, int max_per_rank, int splits_max,
                                                        int rank, int world, uint32_t seq, P2pPeers peers,
-                                                       float *__restrict__ out, uint32_t *err, int vec4)
+                                                       float *__restrict__ out, uint32_t *err, int vec4,
+                                                       unsigned long long timeout_ticks)
 {
     const int b = blockIdx.x, sp = blockIdx.y, slot = (int)(seq & 1u);
     const int i0 = sp * P2P_SPLIT, i1 = i0 + P2P_SPLIT < n ? i0 + P2P_SPLIT : n;
@@ -98,8 +105,12 @@ __global__ __launch_bounds__(256) void k_allgather_p2p(const float *__restrict__
         const uint32_t *flag = peers.flags[rank] + ((size_t)slot * world + b) * splits_max + sp;
         const unsigned long long t0 = real_time();
         int good = 1;
-        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-            if (real_time() - t0 > P2P_TIMEOUT_TICKS) { good = 0; break; }
+        for (;;) {
+            const uint32_t f = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (f == seq) break;
+            // a word from a LATER exchange of the same slot: the peer stopped waiting for this rank at some point and has
+            // overwritten the slice -- nothing to wait for
+            if ((int32_t)(f - seq) > 0 || real_time() - t0 > timeout_ticks) { good = 0; break; }
             __builtin_amdgcn_s_sleep(4);
         }
         ok = good;
@@ -158,6 +169,12 @@ static int load_rccl()
     r.lib = lib;
     g_rccl = r;
     return SES_OK;
+}
+
+void comm_p2p_set_timeout(ses_handle *h)
+{
+    if (h->p2p)
+        h->p2p->timeout_ticks = (unsigned long long)(h->tune_comm_p2p_timeout_ms > 0 ? h->tune_comm_p2p_timeout_ms : 60000) * P2P_TICKS_PER_MS;
 }
 
 int comm_release(ses_handle *h)
@@ -247,6 +264,7 @@ int ses_comm_p2p_export(ses_handle *h, int32_t rank, int32_t world, int32_t max_
     ses_p2p *p = new ses_p2p();
     std::memset(p, 0, sizeof *p);
     p->rank = rank; p->world = world;
+    p->timeout_ticks = (unsigned long long)(h->tune_comm_p2p_timeout_ms > 0 ? h->tune_comm_p2p_timeout_ms : 60000) * P2P_TICKS_PER_MS;
     p->max_per_rank = (max_per_rank + 3) / 4 * 4;                     // slots stay 16-byte aligned
     p->splits_max = ceil_div(p->max_per_rank, P2P_SPLIT);
     p->flag_offset = (sizeof(float) * 2 * (size_t)world * p->max_per_rank + 255) / 256 * 256;
@@ -307,6 +325,13 @@ int ses_comm_p2p_info(ses_handle *h, int32_t *world, int32_t *max_per_rank, int3
     return SES_OK;
 }
 
+int ses_comm_p2p_status(ses_handle *h, uint32_t *timed_out_mask)
+{
+    SES_REQUIRE(h && timed_out_mask, "ses_comm_p2p_status: null argument");
+    *timed_out_mask = (h->p2p && h->p2p->err_host) ? *(volatile uint32_t *)h->p2p->err_host : 0u;
+    return SES_OK;
+}
+
 int ses_comm_p2p_detach(ses_handle *h)
 {
     SES_REQUIRE(h, "ses_comm_p2p_detach: null handle");
@@ -325,7 +350,7 @@ int ses_allgather_fitness(ses_handle *h, const float *local, int32_t n_per_rank,
     SES_REQUIRE(n_per_rank >= 1, "ses_allgather_fitness: n_per_rank must be >= 1");
     if (h->p2p && h->p2p->attached && n_per_rank <= h->p2p->max_per_rank && !(h->tune_comm_force_rccl && h->comm)) {
         ses_p2p *p = h->p2p;
-        if (*(volatile uint32_t *)p->err_host != 0u)
+        if (*(volatile uint32_t *)p->err_host != 0u && !h->tune_comm_p2p_keep_going)
             return set_error(SES_ERR_COMM, "ses_allgather_fitness: an earlier peer-store exchange timed out waiting for rank mask 0x%x "
                              "(its output was NaN-filled); detach the transport (ses_comm_p2p_detach) to continue over RCCL",
                              *(volatile uint32_t *)p->err_host);
@@ -341,7 +366,8 @@ int ses_allgather_fitness(ses_handle *h, const float *local, int32_t n_per_rank,
         p->seq += 1;
         const int vec4 = (n_per_rank % 4 == 0) && ((uintptr_t)local % 16 == 0) && ((uintptr_t)all % 16 == 0);
         hipLaunchKernelGGL(k_allgather_p2p, dim3(p->world, ceil_div(n_per_rank, P2P_SPLIT)), dim3(256), 0, h->stream, local,
-                           (int)n_per_rank, p->max_per_rank, p->splits_max, p->rank, p->world, p->seq, peers, all, p->err_dev, vec4);
+                           (int)n_per_rank, p->max_per_rank, p->splits_max, p->rank, p->world, p->seq, peers, all, p->err_dev, vec4,
+                           p->timeout_ticks);
         SES_HIP_TRY(hipGetLastError());
         return SES_OK;
     }

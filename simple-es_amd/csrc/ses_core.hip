@@ -144,7 +144,9 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"lander_offspring_per_wave", &ses_handle::tune_lander_per_wave, 0, 4},
                                  {"box2d_lanes_per_env", &ses_handle::tune_box2d_lpe, 0, 64},
                                  {"es_final_max_chunks", &ses_handle::tune_es_final_max_chunks, 0, 1 << 20},
-                                 {"comm_force_rccl", &ses_handle::tune_comm_force_rccl, 0, 1}};
+                                 {"comm_force_rccl", &ses_handle::tune_comm_force_rccl, 0, 1},
+                                 {"comm_p2p_timeout_ms", &ses_handle::tune_comm_p2p_timeout_ms, 0, 1 << 30},
+                                 {"comm_p2p_keep_going", &ses_handle::tune_comm_p2p_keep_going, 0, 1}};
     for (const Knob &k : knobs) {
         if (std::strcmp(k.name, name) == 0) {
             SES_REQUIRE(value >= k.lo && value <= k.hi, "ses_set_tuning: %s = %d outside [%d, %d]", name, value, k.lo, k.hi);
@@ -155,6 +157,7 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
             SES_REQUIRE(k.field != &ses_handle::tune_box2d_lpe || (value & (value - 1)) == 0,
                         "ses_set_tuning: box2d_lanes_per_env must be 0 or a power of two up to 64");
             h->*(k.field) = value;
+            if (k.field == &ses_handle::tune_comm_p2p_timeout_ms) ses::comm_p2p_set_timeout(h);   // also for a live mailbox
             return SES_OK;
         }
     }

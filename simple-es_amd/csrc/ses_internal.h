@@ -40,6 +40,8 @@ struct ses_handle {
     int tune_es_final_max_chunks;  // ses_openai_generation: up to this many 1024-row chunks the gradient kernel applies Adam itself
     int tune_box2d_lpe;            // lanes per env of the Box2D MLP rollout: 0 = by population size, 1 / 2 / 4 / 8
     int tune_lander_per_wave;      // offspring per wave of the lockstep lander rollout: 0 = by population size, 1 / 2 / 4
+    int tune_comm_p2p_timeout_ms;  // how long a peer-store exchange waits for a peer (0 = the default, 60 s)
+    int tune_comm_p2p_keep_going;  // 1: exchanges continue after a time-out (the host polls ses_comm_p2p_status and recovers)
 };
 
 namespace ses {
@@ -68,5 +70,6 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 int ensure_episode_scratch(ses_handle *h, size_t episodes);
 int ensure_reduce_scratch(ses_handle *h, size_t bytes);
 int comm_release(ses_handle *h);
+void comm_p2p_set_timeout(ses_handle *h);
 
 }  // namespace ses

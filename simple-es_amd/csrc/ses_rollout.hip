@@ -907,6 +907,31 @@ __global__ __launch_bounds__(256) void k_env_step_cartpole_v4(int n4, int max_st
     }
 }
 
+// The env-step kernel's 13 streams with no arithmetic in between (7 x 16-B non-temporal loads, 6 x 16-B non-temporal
+// stores per lane, same grid): what the memory system of THIS box gives this access pattern -- the ceiling bench.py
+// prints next to the env-step kernel (ses_stream_probe).  The action stream is consumed so that no load can be dropped.
+__global__ __launch_bounds__(256) void k_stream_probe13(int n4, f32x4 *__restrict__ x, f32x4 *__restrict__ xd,
+                                                        f32x4 *__restrict__ th, f32x4 *__restrict__ thd,
+                                                        const i32x4 *__restrict__ action, f32x4 *__restrict__ ret,
+                                                        u32x4 *__restrict__ status)
+{
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 vx = __builtin_nontemporal_load(x + i);
+        const f32x4 vxd = __builtin_nontemporal_load(xd + i), vth = __builtin_nontemporal_load(th + i),
+                    vthd = __builtin_nontemporal_load(thd + i), vr = __builtin_nontemporal_load(ret + i);
+        const i32x4 va = __builtin_nontemporal_load(action + i);
+        const u32x4 vs = __builtin_nontemporal_load(status + i);
+        vx[0] += (float)(va[0] & 0);                              // a value-preserving use of the action stream
+        __builtin_nontemporal_store(vx, x + i);
+        __builtin_nontemporal_store(vxd, xd + i);
+        __builtin_nontemporal_store(vth, th + i);
+        __builtin_nontemporal_store(vthd, thd + i);
+        __builtin_nontemporal_store(vr, ret + i);
+        __builtin_nontemporal_store(vs, status + i);
+    }
+}
+
 template <bool FIXED_LENGTH>
 __global__ void k_env_step_cartpole_scalar(int first, int n, int max_step, float *x, float *xd, float *th, float *thd,
                                            const int32_t *action, float *ret, uint32_t *status)
@@ -1288,6 +1313,23 @@ int ses_env_step(ses_handle *h, int32_t n, int32_t mode, float *x, float *xd, fl
             hipLaunchKernelGGL((k_env_step_cartpole_scalar<false>), dim3(blocks), dim3(256), 0, h->stream, first, n,
                                max_step, x, xd, th, thd, action, ret, status);
     }
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+int ses_stream_probe(ses_handle *h, int32_t n, float *x, float *xd, float *th, float *thd, const int32_t *action, float *ret,
+                     uint32_t *status)
+{
+    using namespace ses;
+    SES_REQUIRE(h && x && xd && th && thd && action && ret && status, "ses_stream_probe: null argument");
+    const uintptr_t align = (uintptr_t)x | (uintptr_t)xd | (uintptr_t)th | (uintptr_t)thd | (uintptr_t)action |
+                            (uintptr_t)ret | (uintptr_t)status;
+    SES_REQUIRE(n >= 4 && (n & 3) == 0 && (align & 15u) == 0, "ses_stream_probe: n must be a multiple of 4 and the arrays 16-byte aligned");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    const int n4 = n / 4;
+    const int blocks = ceil_div(n4, 256) < (1 << 20) ? ceil_div(n4, 256) : (1 << 20);   // the env-step kernel's grid
+    hipLaunchKernelGGL(k_stream_probe13, dim3(blocks), dim3(256), 0, h->stream, n4, (f32x4 *)x, (f32x4 *)xd, (f32x4 *)th,
+                       (f32x4 *)thd, (const i32x4 *)action, (f32x4 *)ret, (u32x4 *)status);
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;
 }

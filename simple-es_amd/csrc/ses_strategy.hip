@@ -681,7 +681,9 @@ int ses_openai_generation(ses_handle *h, const float *fitness, int32_t n, uint64
                            seed, gen, P4, partial, best, counter, chunks, h->P, (float)uf, adam_a, mu_in, m_in, v_in, mu_out,
                            m_out, v_out);
     } else {
-        // a separate small launch finishes the update
+        // a separate small launch finishes the update; this layout's partial[] may lie over the ticket counter of a
+        // smaller population's layout, so a cached "counter is zero" no longer holds
+        h->counter_armed = nullptr;
         hipLaunchKernelGGL((k_es_grad_partial_ranked<false>), dim3(quads, chunks), dim3(256), 0, h->stream, rank, fitness, n, 1,
                            seed, gen, P4, partial, best, counter, chunks, h->P, (float)uf, adam_a, mu_in, m_in, v_in, mu_out,
                            m_out, v_out);

@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 from ses import HipES, MODE_EPISODIC, MODE_FIXED_LENGTH
-from ses.parallel import attach_comm
+from ses.parallel import attach_comm, comm_failed, comm_recover
 
 from .abstracts import BaseESLoop
 
@@ -80,6 +80,7 @@ class ESLoop(BaseESLoop):
         self._stamps = [torch.zeros(2, dtype=torch.int64).pin_memory() for _ in range(4)]
         self._prev_tail = 0
         self._tail_stamped = False
+        self._guarded = False
 
     def _init_states(self, gen, shard):
         if self.shared_init:                       # common random numbers: every offspring sees the same resets
@@ -135,8 +136,10 @@ class ESLoop(BaseESLoop):
         self.dev.set_stamp(stamp[0:1])
         strategy = self.offspring_strategy
         sdev = getattr(strategy, "dev", None)
-        self._tail_stamped = sdev is not None and hasattr(sdev, "set_stamp")
-        if self._tail_stamped:
+        # the tail stamp is written by the launch that writes the next population: there is none on a rank that owns no
+        # rows of it (more ranks than offspring), and _report must not wait for one
+        self._tail_stamped = sdev is not None and hasattr(sdev, "set_stamp") and offsprings.shard.n_local > 0
+        if sdev is not None and hasattr(sdev, "set_stamp"):
             sdev.set_stamp(stamp[1:2])
         results = self.rollout(offsprings)
         if hasattr(strategy, "evaluate_async"):
@@ -146,15 +149,19 @@ class ESLoop(BaseESLoop):
             best = _Ready(value)
         return offsprings, best, curr_sigma, stamp
 
-    def _report(self, ep_num, best, curr_sigma, stamp, start_time, rank0):
+    def _report(self, ep_num, best, curr_sigma, stamp, start_time, tail_stamped, rank0):
         """The reference's per-generation bookkeeping (loop.py:85-99) for a generation whose results are in."""
-        best_reward = best.result()                # waits for THAT generation only; the next one is already queued
+        if self._guarded and comm_failed(self.dev):
+            best_reward = float("nan")             # this rank's exchange timed out: the generations since the last boundary will
+        else:                                      # be replayed (run()), there is nothing worth waiting for
+            best_reward = best.result()            # waits for THAT generation only; the next one is already queued
         now = time.time()
         consumed_time = now - max(start_time, self._last_report)    # generations overlap: time between completions
         self._last_report = now
-        spins = 0
-        while self._tail_stamped and int(stamp[1]) == 0 and spins < 200000:   # written a few us after the best reward
-            spins += 1
+        if tail_stamped and int(stamp[1]) == 0:    # written a few us after the best reward: wait, bounded by TIME
+            deadline = time.perf_counter() + 2e-3
+            while int(stamp[1]) == 0 and time.perf_counter() < deadline:
+                pass
         t_roll, t_tail = int(stamp[0]), int(stamp[1])
         if t_roll and t_tail and self._prev_tail and t_roll > self._prev_tail:
             rollout_consumed_time = (t_roll - self._prev_tail) * 1e-8      # GPU time of the rollout phase (100 MHz ticks)
@@ -170,11 +177,15 @@ class ESLoop(BaseESLoop):
         ep5 = sum(self.ep5_rewards) / len(self.ep5_rewards)
         if self._metrics is None:                  # wandb-free metrics: same quantities as loop.py:94-99
             self._metrics = open(self.save_dir + "/metrics.jsonl", "a", buffering=1 << 16)
+            self._metrics_flushed = now
             if self.env_variant:
                 self._metrics.write(json.dumps({"env_variant": self.env_variant}) + "\n")
         self._metrics.write(json.dumps({"episode": ep_num, "best_reward": best_reward, "curr_sigma": curr_sigma,
                                         "ep5_mean_reward": ep5, "time": consumed_time,
                                         "rollout_t": rollout_consumed_time, "eval_t": eval_consumed_time}) + "\n")
+        if now - self._metrics_flushed > 1.0:      # a reader (or a crash) is never more than a second behind; the flush
+            self._metrics.flush()                  # happens while the GPU is busy with the next generation
+            self._metrics_flushed = now
         print(f"episode: {ep_num}, Best reward: {best_reward:.2f}, sigma: {curr_sigma:.3f}, "
               f"time: {consumed_time:.2f}, rollout_t: {rollout_consumed_time:.2f}, "
               f"eval_t: {eval_consumed_time:.2f}")
@@ -185,31 +196,62 @@ class ESLoop(BaseESLoop):
     def run(self):
         """The reference's generation loop (loop.py:52-104).  The host stays one generation ahead of the GPU: the
         prints / metrics of generation g are produced while generation g + 1 is running, so the device never waits
-        for Python.  Every printed value is the one the reference would print for that generation."""
-        offsprings = self.offspring_strategy.init_offspring(self.network, self.env.get_agent_ids())
+        for Python.  Every printed value is the one the reference would print for that generation.
+
+        Multi-GPU: the peer-store all-gather marks an exchange whose peer did not answer within its time-out instead of
+        waiting for ever.  At every boundary (a checkpoint generation, and at least every `comm_check_period`
+        generations) the ranks agree whether that happened anywhere since the last boundary; if it did, every rank drops
+        the transport (the all-gather continues on RCCL / torch.distributed), restores the strategy state of the last
+        boundary and replays from there -- counter-based noise makes the replay bit-identical to an undisturbed run, and
+        no checkpoint is written from a generation that consumed a NaN shard."""
+        try:
+            return self._run()
+        finally:
+            if self._metrics is not None:          # whatever ends the loop (an exception included) leaves the metrics on disk
+                self._metrics.flush()
+
+    comm_check_period = 64
+
+    def _run(self):
+        strategy = self.offspring_strategy
+        offsprings = strategy.init_offspring(self.network, self.env.get_agent_ids())
         rank0 = offsprings.shard.rank == 0
         if rank0 and self.env_variant:
             print(f"note: {self.env.name} runs on this build's restatement of its third-party physics "
                   f"({self.env_variant}; parity with gym / Box2D is unpinned, see README)")
+        guarded = offsprings.shard.world > 1 and hasattr(strategy, "snapshot") and getattr(strategy, "noise", "") == "philox"
+        self._guarded = guarded
+        snap = (0, strategy.snapshot(offsprings), len(self.history), list(self.ep5_rewards)) if guarded else None
         pending = None
         self._last_report = 0.0
-        for ep_num in range(1, self.generation_num + 1):
+        ep_num = 0
+        while ep_num < self.generation_num:
+            ep_num += 1
             start_time = time.time()
             offsprings, best, curr_sigma, events = self.generation(offsprings)
             if pending is not None:
                 self._report(*pending, rank0)
-            pending = (ep_num, best, curr_sigma, events, start_time)
-            if ep_num % self.save_model_period == 0:
-                self._report(*pending, rank0)      # a checkpoint generation is reported before its file is written
+            pending = (ep_num, best, curr_sigma, events, start_time, self._tail_stamped)
+            checkpoint = ep_num % self.save_model_period == 0
+            if checkpoint or (guarded and (ep_num - snap[0] >= self.comm_check_period or ep_num == self.generation_num)):
+                self._report(*pending, rank0)      # a boundary generation is reported before anything is written
                 pending = None
-                if rank0:
-                    elite = self.offspring_strategy.get_elite_model()
+                if guarded:
+                    if comm_recover(self.dev):     # collective: some rank's exchange timed out since the last boundary
+                        ep_num = snap[0]
+                        offsprings = strategy.restore(snap[1])
+                        del self.history[snap[2]:]
+                        self.ep5_rewards.clear()
+                        self.ep5_rewards.extend(snap[3])
+                        self._prefetched, self._prev_tail = None, 0
+                        continue
+                    snap = (ep_num, strategy.snapshot(offsprings), len(self.history), list(self.ep5_rewards))
+                if checkpoint and rank0:
+                    elite = strategy.get_elite_model()
                     torch.save(elite.state_dict(), self.save_dir + "/saved_models" + f"/ep_{ep_num}.pt")
                     self._metrics.flush()
         if pending is not None:
             self._report(*pending, rank0)
-        if self._metrics is not None:
-            self._metrics.flush()
         return offsprings
 
 

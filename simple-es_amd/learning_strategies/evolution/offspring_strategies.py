@@ -238,6 +238,22 @@ class _DeviceStrategy(BaseOffspringStrategy):
         import copy
         return copy.deepcopy(self.network).load_flat(vec.detach().cpu().numpy())
 
+    # ---- roll-back support (ESLoop.run: a multi-GPU exchange that timed out is replayed from the last boundary) -------
+    def snapshot(self, population):
+        """Everything the next generations depend on, as device clones + host scalars, taken while `population` (the
+        group evaluate() has just returned) is the current one.  restore() rebuilds that population bit for bit: the
+        noise is a pure function of (seed, generation key, row, column)."""
+        snap = {"curr_sigma": self.curr_sigma, "pop_gen": population.gen, "pop_sigma": self._last["sigma"]}
+        snap.update(self._snapshot_state())
+        return snap
+
+    def restore(self, snap):
+        if self.noise != "philox":
+            raise RuntimeError("restore() needs counter-based noise (noise='philox')")
+        self.curr_sigma = snap["curr_sigma"]
+        self.gen = snap["pop_gen"]                 # _materialise keys the rows with it and bumps it again
+        return self._restore_state(snap)
+
 
 class simple_genetic(_DeviceStrategy):
     def __init__(self, init_sigma, sigma_decay, elite_num, offspring_num, noise="philox", seed=0):
@@ -276,6 +292,13 @@ class simple_genetic(_DeviceStrategy):
                                    self.curr_sigma)
         self.curr_sigma *= self.sigma_decay       # decays AFTER regeneration (offspring_strategies.py:117-124)
         return pop, best, self.curr_sigma
+
+    def _snapshot_state(self):
+        return {"elite_models": self.elite_models.clone()}
+
+    def _restore_state(self, snap):
+        self.elite_models = snap["elite_models"].clone()
+        return self._gen_offsprings(self.agent_ids, self.elite_models, self.elite_num, self.offspring_num, snap["pop_sigma"])
 
     def get_wandb_cfg(self):
         return dict(init_sigma=self.init_sigma, sigma_decay=self.sigma_decay, elite_num=self.elite_num,
@@ -331,6 +354,17 @@ class simple_evolution(_DeviceStrategy):
         self.curr_sigma *= self.sigma_decay
         pop = self._gen_offsprings(self.agent_ids, self.elite0, self.mu_model, self.curr_sigma, self.offspring_num)
         return pop, best, self.curr_sigma
+
+    def _snapshot_state(self):
+        same = self.elite0 is self.mu_model or self.elite0.data_ptr() == self.mu_model.data_ptr()
+        return {"mu": self.mu_model.clone(), "elite0": None if same else self.elite0.clone(),
+                "alias": self._alias_state.clone()}
+
+    def _restore_state(self, snap):
+        self.mu_model = snap["mu"].clone()
+        self.elite0 = self.mu_model if snap["elite0"] is None else snap["elite0"].clone()
+        self._alias_state = snap["alias"].clone()
+        return self._gen_offsprings(self.agent_ids, self.elite0, self.mu_model, snap["pop_sigma"], self.offspring_num)
 
     def get_wandb_cfg(self):
         return dict(init_sigma=self.init_sigma, elite_num=self.elite_num, offspring_num=self.offspring_num)
@@ -408,6 +442,17 @@ class openai_es(_DeviceStrategy):
         pop = Population(theta, shard, self.network, self.agent_ids, self.gen)
         self.gen += 1
         return pop, best, self.curr_sigma
+
+    def _snapshot_state(self):
+        opt = self.optimizer
+        return {"mu": self.mu_model.clone(), "m": opt.m.clone(), "v": opt.v.clone(), "t": opt.t}
+
+    def _restore_state(self, snap):
+        opt = self.optimizer
+        self.mu_model, opt.m, opt.v, opt.t = snap["mu"].clone(), snap["m"].clone(), snap["v"].clone(), snap["t"]
+        opt.pi = self.mu_model
+        self._spare = None
+        return self._gen_offsprings(self.agent_ids, self.mu_model, snap["pop_sigma"], self.offspring_num)
 
     def get_wandb_cfg(self):
         return dict(init_sigma=self.init_sigma, sigma_decay=self.sigma_decay, learning_rate=self.learning_rate,

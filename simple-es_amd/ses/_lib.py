@@ -61,6 +61,7 @@ SIGNATURES = {
     "ses_init_states_uniform": [_vp, _u64, _u64, _i64, _i32, _i32, _i32, _f32, _f32, _vp],
     "ses_policy_forward": [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "ses_env_step": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ses_stream_probe": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ses_rollout": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "ses_rank_center": [_vp, _vp, _i32, _vp, _vp, _vp],
     "ses_es_update_philox": [_vp, _vp, _i32, _i32, _u64, _u64, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
@@ -79,6 +80,7 @@ SIGNATURES = {
     "ses_comm_p2p_export": [_vp, _i32, _i32, _i32, _vp],
     "ses_comm_p2p_attach": [_vp, _vp],
     "ses_comm_p2p_info": [_vp, _vp, _vp, _vp],
+    "ses_comm_p2p_status": [_vp, _vp],
     "ses_comm_p2p_detach": [_vp],
 }
 COMM_ID_BYTES = 128

@@ -186,6 +186,7 @@ class HipES:
         buf = ctypes.create_string_buffer(bytes(unique_id), _lib.COMM_ID_BYTES)
         with _stdout_to_stderr():          # RCCL prints a version banner on stdout when it initialises
             check(self._lib.ses_comm_init(self._h, int(rank), int(world), buf), "ses_comm_init")
+        self._route = None
 
     def comm_info(self):
         """(rank, world, rccl_version_code); world == 0 means the handle has no communicator."""
@@ -195,6 +196,7 @@ class HipES:
 
     def comm_destroy(self):
         check(self._lib.ses_comm_destroy(self._h), "ses_comm_destroy")
+        self._route = None
 
     def comm_p2p_export(self, rank, world, max_per_rank):
         """ses_comm_p2p_export: allocate this rank's mailbox of the peer-store transport; returns the 64 handle bytes the
@@ -206,6 +208,7 @@ class HipES:
     def comm_p2p_attach(self, handles):
         blob = b"".join(bytes(h) for h in handles)
         check(self._lib.ses_comm_p2p_attach(self._h, ctypes.create_string_buffer(blob, len(blob))), "ses_comm_p2p_attach")
+        self._route = None
 
     def comm_p2p_info(self):
         """(world, max_per_rank, exchanges); world == 0 means the peer-store transport is not attached."""
@@ -213,15 +216,32 @@ class HipES:
         check(self._lib.ses_comm_p2p_info(self._h, ctypes.byref(w), ctypes.byref(m), ctypes.byref(x)), "ses_comm_p2p_info")
         return w.value, m.value, x.value
 
+    def comm_p2p_status(self):
+        """Bit mask of the ranks some peer-store exchange of this handle gave up waiting for (0 = all good).  Reads a
+        host-visible word: no stream operation, no synchronisation."""
+        m = ctypes.c_uint32()
+        check(self._lib.ses_comm_p2p_status(self._h, ctypes.byref(m)), "ses_comm_p2p_status")
+        return m.value
+
     def comm_p2p_detach(self):
         check(self._lib.ses_comm_p2p_detach(self._h), "ses_comm_p2p_detach")
+        self._route = None
+
+    def comm_route(self):
+        """(p2p world, p2p floats per rank, rccl world) -- what ses_allgather_fitness has to work with.  Cached: the three
+        ctypes calls cost ~2 us per generation otherwise; attach / detach / comm_init / comm_destroy drop the cache."""
+        r = getattr(self, "_route", None)
+        if r is None:
+            w, cap, _ = self.comm_p2p_info()
+            r = self._route = (w, cap, self.comm_info()[1])
+        return r
 
     def allgather_fitness(self, local, out=None):
         """local float32[n_per_rank] on every rank -> float32[world * n_per_rank], rank-major, identical everywhere.
         Peer stores when that transport is attached and the shard fits its mailbox, RCCL otherwise."""
-        world, cap, _ = self.comm_p2p_info()
+        world, cap, rccl_world = self.comm_route()
         if world < 1 or local.shape[0] > cap:
-            _, world, _ = self.comm_info()                  # (with "comm_force_rccl" both transports span the same ranks)
+            world = rccl_world                              # (with "comm_force_rccl" both transports span the same ranks)
         if world < 1:
             raise SesError("allgather_fitness: the handle has no communicator (comm_init or comm_p2p_attach first)")
         n = local.shape[0]
@@ -299,6 +319,16 @@ class HipES:
         self._chk(status, "status", torch.int32, (n,))   # bit pattern of the uint32 status word
         check(self._lib.ses_env_step(self._h, int(n), int(mode), _ptr(x), _ptr(xd), _ptr(th), _ptr(thd), _ptr(action),
                                      _ptr(ret), _ptr(status)), "ses_env_step")
+
+    def stream_probe(self, x, xd, th, thd, action, ret, status):
+        """ses_stream_probe: the env-step kernel's 13 streams with no arithmetic (values unchanged) -- bench.py's ceiling."""
+        n = x.shape[0]
+        for name, t in (("x", x), ("xd", xd), ("th", th), ("thd", thd), ("ret", ret)):
+            self._chk(t, name, torch.float32, (n,))
+        self._chk(action, "action", torch.int32, (n,))
+        self._chk(status, "status", torch.int32, (n,))
+        check(self._lib.ses_stream_probe(self._h, int(n), _ptr(x), _ptr(xd), _ptr(th), _ptr(thd), _ptr(action), _ptr(ret),
+                                         _ptr(status)), "ses_stream_probe")
 
     # -- fused rollout ------------------------------------------------------------------------
     def rollout(self, theta, init, mode=MODE_EPISODIC, want_episodes=False, fitness=None):

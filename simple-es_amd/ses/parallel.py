@@ -63,6 +63,11 @@ def _attach_p2p(owner, rank, world, group):
     ok = _cpu_group_ok(ok, owner.device, group)            # also: nobody starts the test before everybody has attached
     if ok:
         try:
+            # a wait that times out marks the exchange and the run goes on; ESLoop.run() polls the status word, agrees with
+            # the other ranks at its checkpoint boundaries and rolls back onto the next transport (comm_recover below)
+            owner.set_tuning("comm_p2p_keep_going", 1)
+            if os.environ.get("SES_COMM_P2P_TIMEOUT_MS"):
+                owner.set_tuning("comm_p2p_timeout_ms", int(os.environ["SES_COMM_P2P_TIMEOUT_MS"]))
             n = 257
             mine = torch.arange(n, device=owner.device, dtype=torch.float32) + 1000.0 * (rank + 1)
             got = owner.allgather_fitness(mine).cpu()
@@ -134,6 +139,35 @@ def attach_comm(dev, group=None, allow_single=False):
     return True
 
 
+def comm_failed(dev):
+    """True when a peer-store exchange of this process has given up waiting for a peer (local view, no stream operation)."""
+    owner = getattr(dev, "_comm_owner", None)
+    return bool(owner is not None and owner.comm_route()[0] and owner.comm_p2p_status())
+
+
+def comm_recover(dev, group=None):
+    """COLLECTIVE check of the peer-store transport: did any rank's exchange time out since the last check?  If so every
+    rank drains its stream, drops the transport (ses_comm_p2p_detach) and the all-gather continues on RCCL or, without a
+    communicator, on torch.distributed.  Returns True when that happened: the fitness vectors since the last check may
+    hold NaN shards on some ranks, so the caller must roll back to the state it had then (ESLoop.run does, and replays
+    the generations over the fallback transport: the noise is counter-based, so the replay reproduces them bit for bit)."""
+    owner = getattr(dev, "_comm_owner", None)
+    if not _dist_on() or dist.get_world_size(group) == 1 or owner is None or not owner.comm_route()[0]:
+        return False
+    all_good = _cpu_group_ok(not owner.comm_p2p_status(), owner.device, group)
+    if all_good:
+        return False
+    torch.cuda.synchronize(owner.device)           # exchanges in flight end by themselves (time-out at the latest)
+    mask = owner.comm_p2p_status()
+    dist.barrier(group=group)                      # every rank's kernels are done: nobody frees a mailbox a peer still stores into
+    owner.comm_p2p_detach()
+    dist.barrier(group=group)
+    nxt = "RCCL" if owner.comm_route()[2] else "torch.distributed"
+    print(f"[ses] rank {dist.get_rank(group)}: a peer-store exchange timed out (local mask 0x{mask:x}); the fitness "
+          f"all-gather continues on {nxt}", file=sys.stderr, flush=True)
+    return True
+
+
 def comm_info(dev):
     """(rank, world, rccl_version) of the RCCL communicator behind `dev`'s all-gathers; world 0 = none."""
     owner = getattr(dev, "_comm_owner", None) or dev
@@ -145,10 +179,10 @@ def comm_transport(dev, per_rank=1):
     owner = getattr(dev, "_comm_owner", None)
     if owner is None:
         return "torch"
-    world, cap, _ = owner.comm_p2p_info()
+    world, cap, rccl_world = owner.comm_route()
     if world and per_rank <= cap:
         return "p2p-store"
-    return "rccl" if owner.comm_info()[1] else "torch"
+    return "rccl" if rccl_world else "torch"
 
 
 class Shard:
@@ -172,10 +206,10 @@ class Shard:
             slot = local.new_full((self.per_rank,), float("-inf"))
             slot[: self.n_local] = local
         owner = getattr(dev, "_comm_owner", None) if dev is not None else None
-        if owner is None and dev is not None and dev.comm_info()[1] == self.world:
+        if owner is None and dev is not None and dev.comm_route()[2] == self.world:
             owner = dev                                                  # a handle that was given its own communicator
-        if owner is not None and ((owner.comm_p2p_info()[0] == self.world and self.per_rank <= owner.comm_p2p_info()[1])
-                                  or owner.comm_info()[1] == self.world):
+        route = owner.comm_route() if owner is not None else (0, 0, 0)   # cached on the handle: no ctypes call per generation
+        if (route[0] == self.world and self.per_rank <= route[1]) or route[2] == self.world:
             out = owner.allgather_fitness(slot.contiguous())            # ses_allgather_fitness: peer stores or RCCL
         elif local.is_cuda and dist.get_backend(self.group) == "gloo":
             # test rigs only (several ranks sharing one GPU): stage the 4*N bytes through the host

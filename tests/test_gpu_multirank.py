@@ -54,7 +54,11 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,p2p", [(2, True), (4, True), (2, False)], ids=["2_ranks_peer_stores", "4_ranks_peer_stores", "2_ranks_torch_fallback"])
+# (the GPU boxes admit at most 6 processes on a card and the test runner itself holds a context: 5 ranks is the largest
+#  world this rig can form; the 8-rank layout -- shard boundaries, ragged tail -- is covered on the CPU in
+#  tests/test_host_logic.py)
+@pytest.mark.parametrize("world,p2p", [(2, True), (4, True), (5, True), (2, False)],
+                         ids=["2_ranks_peer_stores", "4_ranks_peer_stores", "5_ranks_peer_stores", "2_ranks_torch_fallback"])
 def test_ranks_equal_one_rank_bitwise(tmp_path, world, p2p):
     script = tmp_path / "w.py"
     script.write_text(WORKER % (ROOT, SRC))
@@ -75,3 +79,130 @@ def test_ranks_equal_one_rank_bitwise(tmp_path, world, p2p):
             transport = open(tmp_path / f"{name}_w{world}_r{r}.transport").read()
             assert transport == ("p2p-store" if p2p else "torch"), (name, r, transport, many.stderr[-2000:])
         assert ref["fits"].shape[0] == 4 and ref["fits"].std() > 0
+
+
+C4_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np, torch
+    sys.path[:0] = [%r, %r]
+    out_dir = sys.argv[1]
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import builder
+    from ses.parallel import comm_transport
+    os.chdir(out_dir)
+    # BASELINE configs[3] per rank: 8192 offspring on every rank, the replicated fitness loop over all world * 8192 rows
+    n = 8192 * world
+    cfg = {"env": {"name": "CartPole-v1", "max_step": 30, "pomdp": False, "seed": 1, "shared_init": True},
+           "network": {"name": "gym_model", "num_state": 4, "num_action": 2, "discrete_action": True, "gru": False},
+           "strategy": {"name": "openai_es", "init_sigma": 0.3, "sigma_decay": 0.99, "learning_rate": 0.05,
+                        "offspring_num": n, "seed": 9}}
+    loop = builder.build_loop(cfg, 3, 1, 2, False, 10 ** 9)
+    pop = loop.offspring_strategy.init_offspring(loop.network, loop.env.get_agent_ids())
+    assert pop.theta.shape[0] == 8192 and pop.shard.first == rank * 8192
+    fits = []
+    for g in range(3):
+        fit = loop.rollout(pop)
+        assert fit.shape[0] == n
+        fits.append(fit.cpu().numpy().copy())
+        pop, best, sigma = loop.offspring_strategy.evaluate(fit)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"c4_r{rank}.npz"), fits=np.stack(fits), mu=loop.offspring_strategy.mu_model.cpu().numpy(),
+             transport=np.array(comm_transport(loop.dev, 8192)))
+    dist.destroy_process_group()
+""")
+
+
+def test_c4_shape_five_ranks_of_8192_rows_over_peer_stores(tmp_path):
+    """The C4 layout on the rig: every rank owns 8192 rows (32 KB shards, two 4096-float slices each), the fitness loop
+    runs replicated over all 40 960 rows (sort + search rank path), peer stores carry the exchange; all ranks end
+    with the same fitness vectors and the same parent, bit for bit."""
+    world = 5
+    script = tmp_path / "c4.py"
+    script.write_text(C4_WORKER % (ROOT, SRC))
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script), str(tmp_path)],
+                         capture_output=True, text=True, timeout=900, env={**os.environ, "SES_COMM_P2P": "1"})
+    assert run.returncode == 0, run.stdout + run.stderr
+    ref = np.load(tmp_path / "c4_r0.npz")
+    assert str(ref["transport"]) == "p2p-store"
+    assert ref["fits"].shape == (3, 8192 * world) and np.isfinite(ref["fits"]).all() and ref["fits"].std() > 0
+    for r in range(1, world):
+        got = np.load(tmp_path / f"c4_r{r}.npz")
+        assert str(got["transport"]) == "p2p-store"
+        assert np.array_equal(got["fits"].view(np.uint32), ref["fits"].view(np.uint32)), r
+        assert np.array_equal(got["mu"].view(np.uint32), ref["mu"].view(np.uint32)), r
+
+
+FREEZE_WORKER = textwrap.dedent("""
+    import contextlib, io, os, sys, time
+    import numpy as np, torch
+    sys.path[:0] = [%r, %r]
+    out_dir, world = sys.argv[1], int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    rank = int(os.environ.get("RANK", "0"))
+    import builder
+    from learning_strategies.evolution.loop import ESLoop
+    from ses.parallel import comm_transport
+    ESLoop.comm_check_period = 4
+    os.chdir(out_dir)
+    for name, n in (("openai_es", 203), ("simple_evolution", 96), ("simple_genetic", 120)):
+        cfg = {"env": {"name": "CartPole-v1", "max_step": 100, "pomdp": False, "seed": 3},
+               "network": {"name": "gym_model", "num_state": 4, "num_action": 2, "discrete_action": True, "gru": False},
+               "strategy": {"name": name, "init_sigma": 0.5, "sigma_decay": 0.99, "learning_rate": 0.05,
+                            "elite_num": 8, "offspring_num": n, "seed": 5}}
+        loop = builder.build_loop(cfg, 12, 1, 3, False, 8)
+        before = comm_transport(loop.dev) if world > 1 else "none"
+        calls = [0]
+        orig = loop.generation
+        def generation(pop, _o=orig):
+            calls[0] += 1
+            if world > 1 and rank == 1 and calls[0] == 6 and name == "openai_es":
+                torch.cuda.synchronize()
+                time.sleep(1.5)                      # this rank freezes for five time-outs of its peer
+            return _o(pop)
+        loop.generation = generation
+        with contextlib.redirect_stdout(io.StringIO()):
+            loop.run()
+        after = comm_transport(loop.dev) if world > 1 else "none"
+        elite = loop.offspring_strategy.get_elite_model().flat()
+        saved = sorted(os.listdir(os.path.join(loop.save_dir, "saved_models"))) if loop.save_dir else []
+        np.savez(os.path.join(out_dir, f"fz_{name}_w{world}_r{rank}.npz"), elite=elite, best=np.array([b for b, _ in loop.history]),
+                 sigma=np.array([s for _, s in loop.history]), transports=np.array([before, after]), calls=calls[0],
+                 saved=np.array(saved))
+    if world > 1:
+        dist.destroy_process_group()
+""")
+
+
+def test_a_frozen_rank_costs_a_rollback_not_the_run(tmp_path):
+    """One rank stalls for 1.5 s while its peer's exchanges give up after 0.3 s (SES_COMM_P2P_TIMEOUT_MS): the run is not
+    killed and nothing diverges silently -- at the next boundary the ranks agree that an exchange failed, drop the
+    peer-store transport (torch.distributed carries the all-gather from there on this rig), roll back to the last
+    boundary and replay.  History, sigma trace and final parent equal the undisturbed one-rank run bit for bit, and
+    the strategies that ran afterwards (no transport left) are equal too."""
+    script = tmp_path / "fz.py"
+    script.write_text(FREEZE_WORKER % (ROOT, SRC))
+    one = subprocess.run([sys.executable, str(script), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stdout + one.stderr
+    env = {**os.environ, "SES_COMM_P2P": "1", "SES_COMM_P2P_TIMEOUT_MS": "300"}
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script), str(tmp_path)],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stdout + two.stderr
+    assert "timed out" in two.stderr
+    for name in ("openai_es", "simple_evolution", "simple_genetic"):
+        ref = np.load(tmp_path / f"fz_{name}_w1_r0.npz")
+        for r in range(2):
+            got = np.load(tmp_path / f"fz_{name}_w2_r{r}.npz")
+            assert np.array_equal(got["elite"].view(np.uint32), ref["elite"].view(np.uint32)), (name, r)
+            assert np.array_equal(got["best"], ref["best"]) and np.array_equal(got["sigma"], ref["sigma"]), (name, r)
+            if name == "openai_es":
+                assert list(got["transports"]) == ["p2p-store", "torch"], got["transports"]
+                assert int(got["calls"]) > 12                     # generations were replayed
+            else:
+                assert list(got["transports"]) == ["torch", "torch"]
+        assert list(np.load(tmp_path / f"fz_{name}_w2_r0.npz")["saved"]) == ["ep_8.pt"]

@@ -64,6 +64,18 @@ def test_fitness_allgather_world_size_2_gloo(tmp_path):
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
 
 
+def test_fitness_allgather_world_size_8_gloo(tmp_path):
+    """The 8-rank layout of BASELINE configs[3] on the CPU (gloo): 65 536 rows = 8 x 8192, and the ragged cases
+    (last ranks padded with -inf, ranks that own nothing) -- the shard arithmetic of ses/parallel.py, no GPU."""
+    script = tmp_path / "w8.py"
+    script.write_text(WORKER.replace("(10, 7, 1, 2, 4096)", "(65536, 4097, 10, 3)") % SRC)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script), str(tmp_path)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=480)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert all((tmp_path / f"rank{r}.ok").exists() for r in range(8))
+
+
 def test_bench_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` without a launcher: the parent starts torch.distributed.run as a child, relays
     rank 0's JSON line and returns the child's exit code (here the ranks only rendezvous: no GPU in this container)."""

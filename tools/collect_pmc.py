@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import kernel_hash  # noqa: E402
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 out = {"command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 5 "
                   "--warmup 1 (two separate passes, tools/prof_pmc.sh; summarised by tools/collect_pmc.py)",
        "kernel": "void ses::k_env_step_cartpole_v4<true>", "n_env": 1 << 24, "all_kernels": {}}
@@ -34,6 +34,7 @@ out["gfx950_correction"] = ("FETCH_SIZE counts 128-B requests at 64 B for 16 B/l
 out["traffic_bytes_per_launch"] = (2.0 * out["FETCH_SIZE_avg_KB"] + out["WRITE_SIZE_avg_KB"]) * 1024.0
 out["algorithmic_bytes_per_launch"] = 52 * out["n_env"]
 out["traffic_over_algorithmic"] = out["traffic_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
+out["kernel_match"] = "k_env_step_cartpole_v4"
 out["kernel_code_sha256"] = kernel_hash.hash_kernels(os.path.join(ROOT, "simple-es_amd", "libses_hip.so"),
                                                      "k_env_step_cartpole_v4")
 json.dump(out, open(os.path.join(ROOT, "profiles", TAG + "_pmc_env_step.json"), "w"), indent=1)

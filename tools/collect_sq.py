@@ -51,6 +51,7 @@ def main():
             rec["active_inst_any_frac_of_wave_cycles"] = per["SQ_ACTIVE_INST_ANY"] / per["SQ_WAVE_CYCLES"]
         out["kernels"][k] = rec
     out["peak_valu_wave_instr_per_s"] = PEAK_VALU
+    out["kernel_match"] = match           # the name fragment the hash is taken over (tests/test_profiles_current.py)
     out["kernel_code_sha256"] = kernel_hash.hash_kernels(os.path.join(ROOT, "simple-es_amd", "libses_hip.so"), match)
     # bench.py reads per_dispatch of the first (dominant) kernel at the top level
     if out["kernels"]:
