@@ -161,6 +161,27 @@ int ses_policy_forward(ses_handle *h, const float *theta, const float *obs, floa
 int ses_env_step(ses_handle *h, int32_t n, int32_t mode, float *x, float *xd, float *th, float *thd,
                  const int32_t *action, float *ret, uint32_t *status);
 
+/* ---- step-wise env entry for every env (envs/gym_wrapper.py:23-45, envs/pettingzoo_wrapper.py:22-58) ------------------ */
+/* `env.reset()` / `env.step(action)` of the reference's wrappers for n independent envs, one lane = one env, through the
+ * SAME device functions the fused rollouts call (csrc/ses_envs.hip).  The state of an env is an opaque blob of
+ * ses_env_state_bytes(h) bytes in caller-owned device memory (CartPole 16 B; simple_spread 24 * n_agents + 4; LunarLander /
+ * BipedalWalker: the Box2D-style world of the env followed by the episode's terrain heights).
+ *   ses_env_reset:  init[n, W] (W as for ses_rollout: CartPole 4, simple_spread 4 * n_agents, LunarLander 16, BipedalWalker 4)
+ *                   -> state[n], obs[n, ses_env_obs_width(h)]  (simple_spread: [n, n_agents, 6 * n_agents]); the Box2D envs
+ *                   end their reset with gym's no-op step.
+ *   ses_env_step_generic: action = int32[n] (CartPole), int32[n, n_agents] (simple_spread) or float32[n, num_action]
+ *                   (LunarLander uses components 0 and 1; BipedalWalker all four), already in the env's
+ *                   action space (the policy's tanh output) -> obs, reward[n] (simple_spread: the team reward of the cycle,
+ *                   pettingzoo_wrapper.py:45-52), done[n] = the ENV's own termination (CartPole: |x| > 2.4 or |th| > 12
+ *                   deg; simple_spread: after 25 cycles; Box2D: crash / out of bounds / asleep).  Truncation at env.max_step is
+ *                   the wrapper's (gym_wrapper.py:37-39).  POMDP handles zero the masked observation components
+ *                   (gym_wrapper.py:57-77).  A finished env may be stepped on (its state keeps evolving); callers reset it. */
+int ses_env_state_bytes(ses_handle *h);
+int ses_env_obs_width(ses_handle *h);
+int ses_env_reset(ses_handle *h, const float *init, int32_t n, void *state, float *obs);
+int ses_env_step_generic(ses_handle *h, void *state, const void *action, int32_t n, float *obs, float *reward,
+                         int32_t *done);
+
 /* Measurement aid for the roofline of ses_env_step (no reference counterpart): the same 13 streams -- 7 x 16-byte
  * non-temporal loads and 6 x 16-byte non-temporal stores per lane over the same arrays, same grid -- with no arithmetic
  * in between; every value is written back unchanged.  Its duration is what the memory system of the box gives this
@@ -242,6 +263,56 @@ int ses_elite_select(ses_handle *h, const int32_t *rank, int32_t n, int32_t k, c
 int ses_elite_mean(ses_handle *h, const float *rows, const int32_t *alias_first, int32_t k, float *mean);
 /* dst[i,:] = src[ids[i],:] */
 int ses_gather_rows(ses_handle *h, const float *src, const int32_t *ids, int32_t n_ids, float *dst);
+
+/* ---- k whole generations per call (learning_strategies/evolution/loop.py:61-104 from C) ------------------------------------ */
+/*
+ * The generation loop of ESLoop.run() -- env resets, fused rollout, episode mean, strategy.evaluate, next population -- for
+ * k generations in ONE call: the same entry points as above issued back to back from C, with the strategies' host-side
+ * scalars (sigma decay, Adam's step scale, generation keys) advanced exactly as the Python classes advance them, so the
+ * results are bit-identical to k per-generation calls.  Why: a generation of the reference's own configs (96-240
+ * offspring) is 60-120 us of kernels and took ~96 us of Python to enqueue; from C the device is the limit.
+ * Single process (no all-gather inside); counter-based noise only.  Everything is enqueued, nothing is waited for.
+ *
+ * ses_gen_state: the caller fills the fixed part and the buffers once, the call advances the rest in place:
+ *   strategy            SES_STRATEGY_*
+ *   n                   population rows: openai_es offspring_num (row 0 = mu); simple_evolution offspring_num + 1
+ *                       ([mu, elite0, children]); simple_genetic elite_num * (offspring_num / elite_num)
+ *   theta[2], parents[2], adam_m[2], adam_v[2]   ping-pong halves, `cur` says which holds the current generation's;
+ *                       parents: mu[P] (openai_es, simple_evolution) or elites[elite_num, P] (simple_genetic)
+ *   parent_map          int32[n] on the device, the strategy's constant map as for ses_perturb (elite strategies)
+ *   alias_state         int32[1] on the device (simple_evolution, see ses_elite_select)
+ *   fitness[n], init[(shared_init ? 1 : n) * E * init_width], work_i32[n + 3 * elite_num], work_f32[elite_num * P]
+ *   sigma / pop_sigma   curr_sigma of the strategy / the sigma the current population was drawn with
+ *   pop_gen             generation key of the current population (its noise and its env resets)
+ *   adam_t              Adam's step counter
+ * best: float[k], device or PINNED HOST memory (the kernels store straight into it) <- max(fitness) of each generation;
+ * stamps: optional uint64[k][2] in device-visible memory <- the GPU's 100 MHz counter at the end of each rollout phase and
+ * at the start of the launch that writes the next population (ses_set_stamp).  The handle's own stamp is left as it was.
+ */
+#define SES_STRATEGY_OPENAI_ES 0        /* offspring_strategies.py:262-434 */
+#define SES_STRATEGY_SIMPLE_EVOLUTION 1 /* offspring_strategies.py:128-259 */
+#define SES_STRATEGY_SIMPLE_GENETIC 2   /* offspring_strategies.py:11-125  */
+typedef struct ses_gen_state {
+    int32_t strategy, n, elite_num, mode, shared_init, init_width;
+    float init_lo, init_hi;
+    uint64_t seed, env_seed;
+    double learning_rate, sigma_decay;
+    double sigma, pop_sigma;
+    uint64_t pop_gen;
+    int64_t adam_t;
+    int32_t cur, reserved;
+    float *theta[2];
+    float *parents[2];
+    float *adam_m[2];
+    float *adam_v[2];
+    int32_t *parent_map;
+    int32_t *alias_state;
+    float *fitness;
+    float *init;
+    int32_t *work_i32;
+    float *work_f32;
+} ses_gen_state;
+int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best, uint64_t *stamps);
 
 /* ---- multi-GPU: fitness all-gather over RCCL (replaces the gather half of Pool.map, loop.py:66-79) ---------- */
 /*

@@ -1,0 +1,95 @@
+// ses_generations.hip -- k whole generations in ONE call of the C ABI (ses_run_generations).
+//
+// The reference's generation loop (learning_strategies/evolution/loop.py:61-104) runs one `p.map(RolloutWorker, ...)`
+// and one `strategy.evaluate(results)` per generation from Python.  On the device a generation of the reference's own
+// configs (96-240 offspring) is 60-120 us of kernels, and the Python host needs ~96 us to enqueue it (ctypes calls,
+// tensor bookkeeping): conf/cartpole.yaml and conf/simplespread.yaml ran at half the device's speed.  This file is the
+// same sequence of entry points -- resets, fused rollout, episode mean, the strategy's tail, the next population --
+// issued from C with the host-side scalars of the strategies (sigma decay, Adam's step scale, generation keys) advanced
+// exactly as the Python classes advance them (double arithmetic, same libm pow / sqrt), so a run through this call is
+// bit-identical to the per-generation path (tests/test_gpu_host_mirror.py).  No kernel lives here.
+#include <cmath>
+#include <cstring>
+
+#include "ses_internal.h"
+
+extern "C" {
+
+int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best, uint64_t *stamps)
+{
+    using namespace ses;
+    SES_REQUIRE(h && st && best, "ses_run_generations: null argument");
+    SES_REQUIRE(k >= 1, "ses_run_generations: k must be >= 1");
+    SES_REQUIRE(st->strategy == SES_STRATEGY_OPENAI_ES || st->strategy == SES_STRATEGY_SIMPLE_EVOLUTION ||
+                    st->strategy == SES_STRATEGY_SIMPLE_GENETIC, "ses_run_generations: unknown strategy %d", st->strategy);
+    SES_REQUIRE(st->n >= 2 && (st->cur == 0 || st->cur == 1), "ses_run_generations: bad population size / buffer index");
+    SES_REQUIRE(st->theta[0] && st->theta[1] && st->parents[0] && st->parents[1] && st->fitness && st->init,
+                "ses_run_generations: null buffer");
+    const bool openai = st->strategy == SES_STRATEGY_OPENAI_ES;
+    if (openai) {
+        SES_REQUIRE(st->adam_m[0] && st->adam_m[1] && st->adam_v[0] && st->adam_v[1], "ses_run_generations: openai_es needs the Adam buffers");
+    } else {
+        SES_REQUIRE(st->elite_num >= 1 && st->elite_num <= st->n && st->elite_num <= 1024 && st->parent_map && st->work_i32 &&
+                        st->work_f32, "ses_run_generations: elite strategies need elite_num, parent_map and the work buffers");
+        SES_REQUIRE(st->strategy != SES_STRATEGY_SIMPLE_EVOLUTION || st->alias_state, "ses_run_generations: simple_evolution needs alias_state");
+    }
+    unsigned long long *const saved_stamp = h->stamp;
+    const int n = st->n, ke = st->elite_num;
+    int rc = SES_OK;
+    for (int g = 0; g < k && rc == SES_OK; ++g) {
+        const int cur = st->cur, nxt = cur ^ 1;
+        // env resets of this population (keyed by its generation counter, like ESLoop._init_states)
+        rc = ses_init_states_uniform(h, st->env_seed, st->pop_gen, 0, st->shared_init ? 1 : n, st->shared_init, st->init_width,
+                                     st->init_lo, st->init_hi, st->init);
+        if (rc != SES_OK) break;
+        h->stamp = stamps ? (unsigned long long *)(stamps + 2 * g) : nullptr;          // end of the rollout phase
+        rc = ses_rollout(h, st->theta[cur], st->init, st->shared_init ? 0 : 1, n, st->mode, st->fitness, nullptr, nullptr);
+        if (rc != SES_OK) break;
+        unsigned long long *const tail_stamp = stamps ? (unsigned long long *)(stamps + 2 * g + 1) : nullptr;
+        if (openai) {
+            // optimizers.py:43-47 via Adam.next_step_scale(); offspring_strategies.py _evaluate_fused
+            st->adam_t += 1;
+            const double t = (double)st->adam_t;
+            const double a = st->learning_rate * std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.99, t));
+            const double sigma = st->sigma;
+            st->sigma = st->sigma * st->sigma_decay;
+            h->stamp = tail_stamp;
+            rc = ses_openai_generation(h, st->fitness, n, st->seed, st->pop_gen, st->learning_rate, sigma, a, st->parents[cur],
+                                       st->adam_m[cur], st->adam_v[cur], st->parents[nxt], st->adam_m[nxt], st->adam_v[nxt],
+                                       (float)st->sigma, st->pop_gen + 1, 0, n, st->theta[nxt], best + g);
+            st->pop_sigma = st->sigma;
+        } else {
+            int32_t *rank = st->work_i32, *ids = rank + n, *pidx = ids + ke, *alias = pidx + ke;
+            const bool evo = st->strategy == SES_STRATEGY_SIMPLE_EVOLUTION;
+            rc = ses_rank_center(h, st->fitness, n, rank, nullptr, best + g);
+            if (rc == SES_OK)
+                rc = ses_elite_select(h, rank, n, ke, st->parent_map, evo ? st->alias_state : nullptr, ids, pidx, evo ? alias : nullptr);
+            h->stamp = nullptr;                                                         // the elite rows are not "the next population"
+            // the elite rows of the CURRENT population, rebuilt from (parents, parent map entry, row id): _select_elites
+            float *rows = evo ? st->work_f32 : st->parents[nxt];
+            if (rc == SES_OK)
+                rc = ses_perturb(h, st->parents[cur], pidx, ids, (float)st->pop_sigma, st->seed, st->pop_gen, 0, ke, rows);
+            if (evo) {
+                // mu = elite[0] = the reference's in-place elite sum (offspring_strategies.py:234-248), sigma decays BEFORE the
+                // next population is drawn
+                if (rc == SES_OK) rc = ses_elite_mean(h, rows, alias, ke, st->parents[nxt]);
+                st->sigma = st->sigma * st->sigma_decay;
+                st->pop_sigma = st->sigma;
+            } else {
+                // simple_genetic: the elites are the parents; sigma decays AFTER regeneration (offspring_strategies.py:117-124)
+                st->pop_sigma = st->sigma;
+                st->sigma = st->sigma * st->sigma_decay;
+            }
+            h->stamp = tail_stamp;
+            if (rc == SES_OK)
+                rc = ses_perturb(h, st->parents[nxt], st->parent_map, nullptr, (float)st->pop_sigma, st->seed, st->pop_gen + 1, 0, n,
+                                 st->theta[nxt]);
+        }
+        st->pop_gen += 1;
+        st->cur = nxt;
+    }
+    h->stamp = saved_stamp;
+    return rc;
+}
+
+}  // extern "C"

@@ -3,7 +3,8 @@
 The reference wraps a gym env object; gym's physics is third-party Python.  Here the env IS a gfx950
 kernel: the population rollout never calls this object step by step (ESLoop hands the whole shard to the
 fused rollout kernel), it only reads `name / max_step / pomdp`.  `reset()` / `step()` keep the reference's
-dict protocol for single-env use (checkpoint playback) and run one-lane launches of ses_env_step.
+dict protocol for single-env use (checkpoint playback, the reference's test.py loop) for EVERY supported env:
+one-lane launches of ses_env_reset / ses_env_step_generic, i.e. the same device functions the fused rollouts call.
 """
 import numpy as np
 import torch
@@ -41,49 +42,47 @@ class GymWrapper:
         self.seed_env = 0
         self._episode = 0
         self._dev = None
-        self._soa = None
+        self._state = None
 
     def get_agent_ids(self):
         return ["0"]
 
     # ---- single-env protocol (playback) ---------------------------------------------------------
     def _device(self):
-        if "CartPole" not in self.name:
-            raise NotImplementedError(f"step-wise {self.name} is not exposed; use ESLoop / RolloutWorker (fused device rollout)")
         if self._dev is None:
             from ses import HipES
-            self._dev = HipES(self.name, 4, 2, True, False, pomdp=self.pomdp, max_step=self.horizon, eval_ep_num=1)
+            sp = self.spec
+            self._dev = HipES(self.name, sp["num_state"], sp["num_action"], sp["discrete"], False, pomdp=self.pomdp,
+                              max_step=self.horizon, eval_ep_num=1)
         return self._dev
 
-    def _obs(self):
-        x, xd, th, thd = (float(t[0].item()) for t in self._soa[:4])
-        obs = np.array([x, xd, th, thd], dtype=np.float32)
-        if self.pomdp:
-            obs[1] = 0
-            obs[3] = 0
-        return obs
-
     def reset(self):
+        """gym_wrapper.py:23-30: {"0": {"state": obs}}; the reset distribution is this library's (the reference never seeds
+        its env): episode k of this object draws row (seed_env, k) of the ENV_INIT Philox stream."""
         dev = self._device()
         self.curr_step = 0
-        s0 = dev.init_states_uniform(self.seed_env, self._episode, 0, 1)[0, 0]
+        init = dev.init_states_uniform(self.seed_env, self._episode, 0, 1)[:, 0].contiguous()     # [1, init_dim]
         self._episode += 1
-        x, xd, th, thd, action, ret, status = dev.alloc_env_soa(4)      # 4 lanes: one vector group, lane 0 is the env
-        for t, v in zip((x, xd, th, thd), s0):
-            t.fill_(float(v))
-        self._soa = (x, xd, th, thd, action, ret, status)
-        return {"0": {"state": self._obs()}}
+        self._state, obs = dev.env_reset(init)
+        return {"0": {"state": obs[0].cpu().numpy()}}
 
     def step(self, action):
+        """gym_wrapper.py:32-45: ({"0": transition}, r, done, info); done = env done or curr_step >= max_step."""
         dev = self._device()
         self.curr_step += 1
-        x, xd, th, thd, act, ret, status = self._soa
-        act.fill_(int(np.asarray(action["0"])))
-        before = float(ret[0].item())
-        dev.env_step(x, xd, th, thd, act, ret, status)
-        r = float(ret[0].item()) - before
-        d = bool(int(status[0].item()) < 0)                              # bit 31 = done
-        tr = {"state": self._obs(), "reward": r, "done": d, "info": {}}
+        a = np.asarray(action["0"])
+        if self.spec["discrete"]:
+            act = torch.tensor([int(a)], dtype=torch.int32, device=dev.device)
+        else:
+            act = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).reshape(1, -1)).to(dev.device)
+        obs, reward, done = dev.env_step_generic(self._state, act)
+        s, r, d = obs[0].cpu().numpy(), float(reward[0].item()), bool(int(done[0].item()))
+        if self.max_step != "None" and self.max_step is not None:
+            if self.curr_step >= int(self.max_step) or d:
+                d = True
+        if self.curr_step >= self.spec["time_limit"]:          # gym's own TimeLimit wrapper around the registered env
+            d = True
+        tr = {"state": s, "reward": r, "done": d, "info": {}}
         return {"0": tr}, r, d, {}
 
     def render(self):

@@ -22,6 +22,122 @@ from ses.parallel import attach_comm, comm_failed, comm_recover
 from .abstracts import BaseESLoop
 
 
+class _GenerationBatch:
+    """The state of a run in the form ses_run_generations advances (include/ses.h: ses_gen_state): device buffers for the
+    ping-pong halves, the strategy's constant parent map, and the host scalars.  `run(k)` enqueues k generations in one
+    C call; `sync_back()` hands the result to the strategy object (so that checkpoints, get_elite_model() and a later
+    per-generation call see exactly what they would have seen)."""
+
+    K_MAX = 32
+
+    @staticmethod
+    def eligible(loop, strategy, population):
+        from learning_strategies.evolution.offspring_strategies import openai_es, simple_evolution, simple_genetic
+        hooked = any(name in loop.__dict__ or getattr(type(loop), name) is not getattr(ESLoop, name)
+                     for name in ("rollout", "generation", "_init_states"))        # a caller observing the per-generation methods
+        return (population.shard.world == 1 and type(strategy) in (openai_es, simple_evolution, simple_genetic)
+                and strategy.noise == "philox" and getattr(strategy, "fused", True) and hasattr(loop.dev, "run_generations")
+                and not hooked and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+                and os.environ.get("SES_BATCH_GENERATIONS", "1") != "0")
+
+    def __init__(self, loop, strategy, population):
+        import numpy as np
+        from learning_strategies.evolution.offspring_strategies import openai_es, simple_evolution
+        from ses import _lib
+        dev, P = loop.dev, strategy.P
+        self.loop, self.strategy, self.dev = loop, strategy, dev
+        n = population.theta.shape[0]
+        st = _lib.SesGenState()
+        self.kind = (_lib.STRATEGY_OPENAI_ES if isinstance(strategy, openai_es) else
+                     _lib.STRATEGY_SIMPLE_EVOLUTION if isinstance(strategy, simple_evolution) else _lib.STRATEGY_SIMPLE_GENETIC)
+        st.strategy, st.n, st.mode = self.kind, n, loop.mode
+        st.elite_num = 0 if self.kind == _lib.STRATEGY_OPENAI_ES else strategy.elite_num
+        st.shared_init, st.init_width = int(loop.shared_init), dev.init_dim
+        st.init_lo, st.init_hi = dev.init_range
+        st.seed, st.env_seed = strategy.seed, loop.seed_env
+        st.learning_rate = getattr(strategy, "learning_rate", 0.0)
+        st.sigma_decay = strategy.sigma_decay
+        st.sigma, st.pop_sigma = strategy.curr_sigma, strategy._last["sigma"]
+        st.pop_gen = population.gen
+        keep = self.keep = {}
+        keep["theta"] = [population.theta.contiguous(), dev.empty(n, P)]
+        if self.kind == _lib.STRATEGY_OPENAI_ES:
+            opt = strategy.optimizer
+            st.adam_t = opt.t
+            keep["parents"] = [strategy.mu_model.clone(), dev.empty(P)]
+            keep["m"] = [opt.m.clone(), dev.empty(P)]
+            keep["v"] = [opt.v.clone(), dev.empty(P)]
+            self.map_host = strategy._last["idx_host"]
+        elif self.kind == _lib.STRATEGY_SIMPLE_EVOLUTION:
+            keep["parents"] = [strategy.mu_model.clone(), dev.empty(P)]       # elite[0] IS mu after every evaluate (and at the start)
+            N = strategy.offspring_num
+
+            def build():
+                idx = np.zeros(N + 1, dtype=np.int32)
+                idx[0], idx[1] = -1, -1
+                return idx
+            self.map_host = strategy._const_map(("evolution", N, True), build)
+            keep["alias"] = strategy._alias_state
+        else:
+            keep["parents"] = [strategy.elite_models.clone().contiguous(), dev.empty(strategy.elite_num, P)]
+            self.map_host = strategy._last["idx_host"]
+        if self.kind != _lib.STRATEGY_OPENAI_ES:
+            keep["map"] = torch.from_numpy(np.ascontiguousarray(self.map_host, dtype=np.int32)).to(dev.device)
+            keep["wi"] = dev.empty(n + 3 * st.elite_num, dtype=torch.int32)
+            keep["wf"] = dev.empty(st.elite_num, P)
+            st.parent_map, st.work_i32, st.work_f32 = keep["map"].data_ptr(), keep["wi"].data_ptr(), keep["wf"].data_ptr()
+            if "alias" in keep:
+                st.alias_state = keep["alias"].data_ptr()
+        keep["fitness"] = dev.empty(n)
+        keep["init"] = dev.empty(1 if loop.shared_init else n, dev.E, dev.init_dim)
+        st.fitness, st.init = keep["fitness"].data_ptr(), keep["init"].data_ptr()
+        for i in (0, 1):
+            st.theta[i], st.parents[i] = keep["theta"][i].data_ptr(), keep["parents"][i].data_ptr()
+            if "m" in keep:
+                st.adam_m[i], st.adam_v[i] = keep["m"][i].data_ptr(), keep["v"][i].data_ptr()
+        st.cur = 0
+        self.st = st
+        self.shard = population.shard
+        # two chunks in flight: pinned rings the kernels store the best reward / the time stamps into
+        self.best = [torch.full((self.K_MAX,), float("nan"), dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.stamps = [torch.zeros(self.K_MAX, 2, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.slot = 0
+
+    def run(self, k):
+        """Enqueue k generations; returns (pinned best[k], pinned stamps[k, 2], [curr_sigma after each generation])."""
+        slot, self.slot = self.slot, self.slot ^ 1
+        best, stamps = self.best[slot], self.stamps[slot]
+        best[:k] = float("nan")
+        stamps[:k].zero_()
+        sigma, sigmas = self.st.sigma, []
+        for _ in range(k):                              # what the C loop does to curr_sigma, for the per-generation prints
+            sigma *= self.st.sigma_decay
+            sigmas.append(sigma)
+        self.dev.run_generations(self.st, k, best, stamps)
+        return best, stamps, sigmas
+
+    def sync_back(self):
+        from learning_strategies.evolution.offspring_strategies import Population
+        from ses import _lib
+        st, s, keep = self.st, self.strategy, self.keep
+        cur = st.cur
+        s.curr_sigma = st.sigma
+        s.gen = int(st.pop_gen) + 1
+        parents = keep["parents"][cur]
+        if self.kind == _lib.STRATEGY_OPENAI_ES:
+            opt = s.optimizer
+            s.mu_model, opt.m, opt.v, opt.t = parents, keep["m"][cur], keep["v"][cur], int(st.adam_t)
+            opt.pi = s.mu_model
+            s._spare = (keep["parents"][cur ^ 1], keep["m"][cur ^ 1], keep["v"][cur ^ 1])
+        elif self.kind == _lib.STRATEGY_SIMPLE_EVOLUTION:
+            s.mu_model = s.elite0 = parents
+        else:
+            s.elite_models = parents
+        s._last = {"parents": parents.view(-1, s.P), "idx_host": self.map_host, "sigma": st.pop_sigma, "gen": int(st.pop_gen),
+                   "shard": self.shard}
+        return Population(keep["theta"][cur], self.shard, s.network, s.agent_ids, int(st.pop_gen))
+
+
 class ESLoop(BaseESLoop):
     def __init__(self, config, offspring_strategy, env, network, generation_num, process_num, eval_ep_num,
                  log=False, save_model_period=10):
@@ -221,6 +337,8 @@ class ESLoop(BaseESLoop):
                   f"({self.env_variant}; parity with gym / Box2D is unpinned, see README)")
         guarded = offsprings.shard.world > 1 and hasattr(strategy, "snapshot") and getattr(strategy, "noise", "") == "philox"
         self._guarded = guarded
+        if _GenerationBatch.eligible(self, strategy, offsprings):
+            return self._run_batched(strategy, offsprings, rank0)
         snap = (0, strategy.snapshot(offsprings), len(self.history), list(self.ep5_rewards)) if guarded else None
         pending = None
         self._last_report = 0.0
@@ -253,6 +371,42 @@ class ESLoop(BaseESLoop):
         if pending is not None:
             self._report(*pending, rank0)
         return offsprings
+
+
+    def _run_batched(self, strategy, offsprings, rank0):
+        """run() on one GPU: the generations go to the device k at a time through ses_run_generations (one C call instead
+        of ~10 Python-level calls per generation), two chunks in flight; prints, metrics and checkpoints as in _run().
+        Bit-identical to the per-generation path (tests/test_gpu_host_mirror.py)."""
+        from learning_strategies.evolution.offspring_strategies import PendingReward
+        batch = _GenerationBatch(self, strategy, offsprings)
+        self._last_report = 0.0
+        ep_num, pending = 0, None
+
+        def report(chunk):
+            first, k, best, stamps, sigmas, t0 = chunk
+            for j in range(k):
+                self._report(first + j, PendingReward(best[j:j + 1]), sigmas[j], stamps[j], t0, True, rank0)
+
+        while ep_num < self.generation_num:
+            to_boundary = self.save_model_period - ep_num % self.save_model_period
+            k = min(batch.K_MAX, self.generation_num - ep_num, to_boundary)
+            t0 = time.time()
+            best, stamps, sigmas = batch.run(k)
+            if pending is not None:
+                report(pending)
+            pending = (ep_num + 1, k, best, stamps, sigmas, t0)
+            ep_num += k
+            if ep_num % self.save_model_period == 0:
+                report(pending)
+                pending = None
+                batch.sync_back()
+                if rank0:
+                    elite = strategy.get_elite_model()
+                    torch.save(elite.state_dict(), self.save_dir + "/saved_models" + f"/ep_{ep_num}.pt")
+                    self._metrics.flush()
+        if pending is not None:
+            report(pending)
+        return batch.sync_back()
 
 
 class _Ready:

@@ -37,6 +37,27 @@ class SesConfig(ctypes.Structure):
     ]
 
 
+class SesGenState(ctypes.Structure):
+    """ses_gen_state of include/ses.h (ses_run_generations)."""
+    _fields_ = [
+        ("strategy", ctypes.c_int32), ("n", ctypes.c_int32), ("elite_num", ctypes.c_int32), ("mode", ctypes.c_int32),
+        ("shared_init", ctypes.c_int32), ("init_width", ctypes.c_int32),
+        ("init_lo", ctypes.c_float), ("init_hi", ctypes.c_float),
+        ("seed", ctypes.c_uint64), ("env_seed", ctypes.c_uint64),
+        ("learning_rate", ctypes.c_double), ("sigma_decay", ctypes.c_double),
+        ("sigma", ctypes.c_double), ("pop_sigma", ctypes.c_double),
+        ("pop_gen", ctypes.c_uint64), ("adam_t", ctypes.c_int64),
+        ("cur", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("theta", ctypes.c_void_p * 2), ("parents", ctypes.c_void_p * 2),
+        ("adam_m", ctypes.c_void_p * 2), ("adam_v", ctypes.c_void_p * 2),
+        ("parent_map", ctypes.c_void_p), ("alias_state", ctypes.c_void_p),
+        ("fitness", ctypes.c_void_p), ("init", ctypes.c_void_p),
+        ("work_i32", ctypes.c_void_p), ("work_f32", ctypes.c_void_p),
+    ]
+
+
+STRATEGY_OPENAI_ES, STRATEGY_SIMPLE_EVOLUTION, STRATEGY_SIMPLE_GENETIC = 0, 1, 2
+
 _vp = ctypes.c_void_p
 _i32 = ctypes.c_int32
 _i64 = ctypes.c_int64
@@ -61,6 +82,10 @@ SIGNATURES = {
     "ses_init_states_uniform": [_vp, _u64, _u64, _i64, _i32, _i32, _i32, _f32, _f32, _vp],
     "ses_policy_forward": [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "ses_env_step": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ses_env_state_bytes": [_vp],
+    "ses_env_obs_width": [_vp],
+    "ses_env_reset": [_vp, _vp, _i32, _vp, _vp],
+    "ses_env_step_generic": [_vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "ses_stream_probe": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ses_rollout": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "ses_rank_center": [_vp, _vp, _i32, _vp, _vp, _vp],
@@ -72,6 +97,7 @@ SIGNATURES = {
     "ses_elite_select": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "ses_elite_mean": [_vp, _vp, _vp, _i32, _vp],
     "ses_gather_rows": [_vp, _vp, _vp, _i32, _vp],
+    "ses_run_generations": [_vp, ctypes.POINTER(SesGenState), _i32, _vp, _vp],
     "ses_comm_unique_id": [_vp],
     "ses_comm_init": [_vp, _i32, _i32, _vp],
     "ses_comm_info": [_vp, _vp, _vp, _vp],

@@ -320,6 +320,59 @@ class HipES:
         check(self._lib.ses_env_step(self._h, int(n), int(mode), _ptr(x), _ptr(xd), _ptr(th), _ptr(thd), _ptr(action),
                                      _ptr(ret), _ptr(status)), "ses_env_step")
 
+    # -- k generations per call (ses_run_generations) ---------------------------------------------------
+    def run_generations(self, state, k, best, stamps=None):
+        """Enqueue k whole generations described by `state` (a _lib.SesGenState the caller keeps alive together with the
+        tensors it points to).  best: pinned host (or device) float32[>= k]; stamps: pinned int64[>= k, 2] or None."""
+        if not (isinstance(best, torch.Tensor) and best.dtype == torch.float32 and best.numel() >= k and best.is_contiguous()
+                and (best.is_pinned() if best.device.type == "cpu" else best.device == self.device)):
+            raise SesError("run_generations: best must be a pinned host or device float32 tensor of at least k elements")
+        if stamps is not None and not (isinstance(stamps, torch.Tensor) and stamps.dtype == torch.int64 and stamps.numel() >= 2 * k
+                                       and stamps.is_contiguous()
+                                       and (stamps.is_pinned() if stamps.device.type == "cpu" else stamps.device == self.device)):
+            raise SesError("run_generations: stamps must be a pinned host or device int64 tensor of at least 2 k elements")
+        check(self._lib.ses_run_generations(self._h, ctypes.byref(state), int(k), _ptr(best), _ptr(stamps)), "ses_run_generations")
+
+    # -- step-wise envs (ses_env_reset / ses_env_step_generic) --------------------------------------
+    def env_state_bytes(self):
+        b = self._lib.ses_env_state_bytes(self._h)
+        if b <= 0:
+            check(b, "ses_env_state_bytes")
+        return b
+
+    def env_obs_width(self):
+        w = self._lib.ses_env_obs_width(self._h)
+        if w <= 0:
+            check(w, "ses_env_obs_width")
+        return w
+
+    def env_reset(self, init):
+        """init float32[n, init_dim] -> (state blob uint8[n, state_bytes], obs float32[n, obs_width])."""
+        n = init.shape[0]
+        self._chk(init, "init", torch.float32, (n, self.init_dim))
+        state = torch.zeros(n, self.env_state_bytes(), dtype=torch.uint8, device=self.device)
+        obs = self.empty(n, self.env_obs_width())
+        check(self._lib.ses_env_reset(self._h, _ptr(init), int(n), _ptr(state), _ptr(obs)), "ses_env_reset")
+        return state, obs
+
+    def env_step_generic(self, state, action):
+        """One transition of n envs: (obs float32[n, obs_width], reward float32[n], done int32[n]); the state blob is
+        updated in place.  action: int32[n] (CartPole), int32[n, n_agents] (simple_spread), float32[n, A] (Box2D envs)."""
+        n = state.shape[0]
+        self._chk(state, "state", torch.uint8, (n, self.env_state_bytes()))
+        if self.env_id == ENV_CARTPOLE:
+            self._chk(action, "action", torch.int32, (n,))
+        elif self.env_id == ENV_SIMPLE_SPREAD:
+            self._chk(action, "action", torch.int32, (n, self.n_agents))
+        else:
+            self._chk(action, "action", torch.float32, (n, self.A))
+        obs = self.empty(n, self.env_obs_width())
+        reward = self.empty(n)
+        done = self.empty(n, dtype=torch.int32)
+        check(self._lib.ses_env_step_generic(self._h, _ptr(state), _ptr(action), int(n), _ptr(obs), _ptr(reward), _ptr(done)),
+              "ses_env_step_generic")
+        return obs, reward, done
+
     def stream_probe(self, x, xd, th, thd, action, ret, status):
         """ses_stream_probe: the env-step kernel's 13 streams with no arithmetic (values unchanged) -- bench.py's ceiling."""
         n = x.shape[0]
