@@ -20,7 +20,10 @@ HIDDEN = 32
 
 def build(force=False):
     """Compile the C restatement with the recipe in oracle/Makefile."""
-    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in os.listdir(_HERE) if f.endswith((".c", ".cpp", ".h")))
+    world = os.path.join(os.path.dirname(_HERE), "simple-es_amd", "csrc")       # the Box2D-style world: one text, owned by the product
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".cpp", ".h"))]
+    srcs += [os.path.join(world, f) for f in ("ses_b2.h", "ses_b2_toi.h", "ses_b2_shapes.h", "ses_lander_env.h", "ses_walker_env.h")]
+    src_m = max(os.path.getmtime(f) for f in srcs)
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m:
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _SO

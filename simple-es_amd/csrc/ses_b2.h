@@ -1,12 +1,13 @@
 // ses_b2.h -- a small rigid-body world in the manner of Box2D 2.3.0 (the engine behind gym's Box2D envs, reached
 // by the reference through envs/gym_wrapper.py:9,36 for LunarLanderContinuous-v2 / BipedalWalker-v3).
 //
-// THIS FILE EXISTS TWICE, BYTE-IDENTICAL (tests/test_oracle_lander.py checks it): oracle/ses_b2.h is test
-// infrastructure, compiled for the host by oracle/ses_b2_oracle.cpp; simple-es_amd/csrc/ses_b2.h is the product,
-// compiled for gfx950 by csrc/ses_lander.h.  The including file supplies the B2_* macros (function qualifiers, sincos,
-// sqrt).  One text, so that every float operation happens in the same order on both sides and the GPU
-// rollouts can be compared with the CPU's bit for bit; what the comparison then pins is the device build (LDS terrain,
-// wave-level control flow, the compiler), the physics itself is covered by the behavioural tests.
+// ONE TEXT, COMPILED TWICE: for gfx950 by csrc/ses_lander.h / ses_walker.h (the product) and for the host by
+// oracle/ses_b2_oracle.cpp (test infrastructure; oracle/Makefile adds -I simple-es_amd/csrc).  The including file supplies
+// the B2_* macros (function qualifiers, sincos, sqrt).  One text, so that every float operation happens in the same
+// order on both sides and the GPU rollouts can be compared with the CPU's bit for bit; what THAT comparison pins is the
+// device build (LDS terrain, wave-level control flow, the compiler).  The physics itself is checked by the behavioural
+// tests and against an independently written float64 integration of the lander (oracle/lander64.py,
+// tests/test_oracle_lander.py::test_independent_float64_lander_envelope).
 //
 // Box2D itself is third-party, absent from the reference tree and from this image: PARITY WITH BOX2D IS UNPINNED.
 // What is restated, from the published Box2D 2.3.0 algorithms (file / function names in the comments below):

@@ -3,8 +3,8 @@
 // advancement with a bracketed root finder).  Included by ses_b2.h; the world-level sub-stepping (b2World::SolveTOI,
 // b2Island::SolveTOI) is there.
 //
-// THIS FILE EXISTS TWICE, BYTE-IDENTICAL, like ses_b2.h (see there): oracle/ = test infrastructure (host build),
-// simple-es_amd/csrc/ = product (gfx950 build).  PARITY WITH BOX2D IS UNPINNED (Box2D is not in the reference tree nor in
+// One text compiled twice, like ses_b2.h (see there): for gfx950 by the product, for the host by oracle/ses_b2_oracle.cpp
+// (test infrastructure, -I simple-es_amd/csrc).  PARITY WITH BOX2D IS UNPINNED (Box2D is not in the reference tree nor in
 // this image): what follows restates the published algorithms of b2Distance.cpp and b2TimeOfImpact.cpp for the one pair
 // of shapes these worlds have -- proxy A = a terrain edge (two vertices, in world coordinates: the terrain body's
 // transform is the identity and it never moves), proxy B = a body's convex polygon (<= 6 vertices, swept from

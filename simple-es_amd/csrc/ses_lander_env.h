@@ -4,8 +4,8 @@
 // "spring", ten terrain edges, world.Step(1/50, 6*30, 2*30) per env step, engines as impulses at the nozzle positions
 // with per-step dispersion noise, gym's observation / shaping reward / termination rules.
 //
-// THIS FILE EXISTS TWICE, BYTE-IDENTICAL, like ses_b2.h (see there): oracle/ = test infrastructure (host build),
-// simple-es_amd/csrc/ = product (gfx950 build).
+// One text compiled twice, like ses_b2.h (see there): for gfx950 by the product, for the host by oracle/ses_b2_oracle.cpp
+// (test infrastructure, -I simple-es_amd/csrc).
 // gym and Box2D are third-party and absent here: PARITY UNPINNED at this boundary (see ses_b2.h for the list of
 // deviations).  Env-level deviations: gym evaluates the engine geometry and the observation in Python doubles, here
 // everything is float32; np_random is replaced by a row of 16 uniforms per episode ([0,1] initial force, [2..13] terrain

@@ -909,7 +909,8 @@ __global__ __launch_bounds__(256) void k_env_step_cartpole_v4(int n4, int max_st
 
 // The env-step kernel's 13 streams with no arithmetic in between (7 x 16-B non-temporal loads, 6 x 16-B non-temporal
 // stores per lane, same grid): what the memory system of THIS box gives this access pattern -- the ceiling bench.py
-// prints next to the env-step kernel (ses_stream_probe).  The action stream is consumed so that no load can be dropped.
+// prints next to the env-step kernel (ses_stream_probe).  Every loaded vector passes through an empty asm statement, so
+// that neither a load nor a store-back of an unchanged value can be dropped (tests/test_profiles_current.py counts them).
 __global__ __launch_bounds__(256) void k_stream_probe13(int n4, f32x4 *__restrict__ x, f32x4 *__restrict__ xd,
                                                         f32x4 *__restrict__ th, f32x4 *__restrict__ thd,
                                                         const i32x4 *__restrict__ action, f32x4 *__restrict__ ret,
@@ -922,13 +923,17 @@ __global__ __launch_bounds__(256) void k_stream_probe13(int n4, f32x4 *__restric
                     vthd = __builtin_nontemporal_load(thd + i), vr = __builtin_nontemporal_load(ret + i);
         const i32x4 va = __builtin_nontemporal_load(action + i);
         const u32x4 vs = __builtin_nontemporal_load(status + i);
-        vx[0] += (float)(va[0] & 0);                              // a value-preserving use of the action stream
+        asm volatile("" ::"v"(va));                               // the action stream is loaded (and consumed here), never stored
+        // opaque to the optimiser: without this, storing a value back to the address it was loaded from is dropped
+        f32x4 wxd = vxd, wth = vth, wthd = vthd, wr = vr;
+        u32x4 ws = vs;
+        asm volatile("" : "+v"(vx), "+v"(wxd), "+v"(wth), "+v"(wthd), "+v"(wr), "+v"(ws));
         __builtin_nontemporal_store(vx, x + i);
-        __builtin_nontemporal_store(vxd, xd + i);
-        __builtin_nontemporal_store(vth, th + i);
-        __builtin_nontemporal_store(vthd, thd + i);
-        __builtin_nontemporal_store(vr, ret + i);
-        __builtin_nontemporal_store(vs, status + i);
+        __builtin_nontemporal_store(wxd, xd + i);
+        __builtin_nontemporal_store(wth, th + i);
+        __builtin_nontemporal_store(wthd, thd + i);
+        __builtin_nontemporal_store(wr, ret + i);
+        __builtin_nontemporal_store(ws, status + i);
     }
 }
 

@@ -31,7 +31,7 @@ def test_lander_gru_golden_and_oracle(golden_dir):
     assert np.array_equal(ep_steps.cpu().numpy(), o_steps)
     assert np.array_equal(ep_ret.cpu().numpy().view(np.uint64), o_ret.view(np.uint64)), "episode returns differ from the oracle"
     assert np.array_equal(fit.cpu().numpy().view(np.uint32), o_fit.view(np.uint32))
-    np.testing.assert_allclose(fit.cpu().numpy().astype(np.float64), g["returns"], rtol=2e-5, atol=5e-3)
+    np.testing.assert_allclose(fit.cpu().numpy().astype(np.float64), g["returns"], rtol=1e-5, atol=1e-4)   # observed: 7.8e-6 relative
     es.close()
 
 

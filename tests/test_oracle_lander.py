@@ -2,7 +2,6 @@
 against fixture G8 (reference RolloutWorker + reference GRU GymEnvModel with the continuous tanh head, POMDP mask), and
 behavioural checks of the world itself -- joints hold, limits hold, legs carry the hull, the island falls asleep --
 since Box2D is not here to compare with (parity unpinned, see the headers)."""
-import filecmp
 import json
 import os
 
@@ -14,10 +13,11 @@ from oracle.lander_env import LunarLanderEnv
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_world_and_env_headers_are_one_text_in_oracle_and_product():
-    # the oracle and the product compile the same text (host / gfx950); see the header of ses_b2.h
-    for name in ("ses_b2.h", "ses_b2_toi.h", "ses_lander_env.h", "ses_b2_shapes.h"):
-        assert filecmp.cmp(os.path.join(ROOT, "oracle", name), os.path.join(ROOT, "simple-es_amd", "csrc", name), shallow=False), name
+def test_world_and_env_headers_exist_once():
+    # the oracle and the product compile ONE text (host / gfx950); see the header of ses_b2.h and oracle/Makefile
+    for name in ("ses_b2.h", "ses_b2_toi.h", "ses_lander_env.h", "ses_walker_env.h", "ses_b2_shapes.h"):
+        assert os.path.exists(os.path.join(ROOT, "simple-es_amd", "csrc", name)), name
+        assert not os.path.exists(os.path.join(ROOT, "oracle", name)), f"oracle/{name}: the world lives in csrc/ only"
 
 
 def test_g8_returns_match_reference(golden_dir):
@@ -27,7 +27,9 @@ def test_g8_returns_match_reference(golden_dir):
     fit, ep, steps = co.rollout_lander(g["theta"], g["init"], meta["E"], meta["max_step"])
     # continuous control: actions differ from torch's at the 1e-6 level, returns follow smoothly unless an engine
     # threshold (a0 > 0, |a1| > 0.5) or a contact event falls between the two -- none does in this fixture
-    np.testing.assert_allclose(fit.astype(np.float64), g["returns"], rtol=2e-5, atol=5e-3)
+    # Observed: max |difference| 2.3e-3 on returns of -88 ... -1275, max relative difference 7.8e-6: the bound is north_star's
+    # 1e-4 read relatively, tightened to what is seen (round 2 allowed rtol 2e-5 + atol 5e-3).
+    np.testing.assert_allclose(fit.astype(np.float64), g["returns"], rtol=1e-5, atol=1e-4)
     assert steps.max() <= 300 and steps.min() >= 1
 
 
@@ -224,3 +226,78 @@ def test_continuous_collision_stops_fast_legs_at_the_surface():
                     deepest = max(deepest, float((0.99 * 13.333 / 4 - low[on_pad, 1]).max()))   # smoothed pad height
     assert max(speeds) > 4.0                                           # these ARE fast impacts
     assert deepest < 0.04, deepest
+
+
+def test_independent_float64_lander_envelope():
+    """The float32 world against oracle/lander64.c -- an integration written independently of it (double precision, one
+    generic constraint row type, velocity constraints solved to convergence instead of 180 Gauss-Seidel iterations, own
+    mass properties, vertex contacts, no time-of-impact pass) that shares only the INPUTS: the reset row, the per-step
+    engine-dispersion numbers, the actions.  Both start from the configuration the float32 world is in after gym's leg
+    snap (lander64.c, l64_adopt, says why).  The CPU build of the float32 world is bit-identical to the device kernels
+    (tests/test_gpu_lander.py, test_gpu_envs.py), so this bounds the device trajectories too.
+
+    ENVELOPE (observed maxima in brackets), 30 open-loop flights of 65-135 steps with piecewise-constant random engines
+    and 20 closed-loop landings with gym's heuristic:
+      flight: at every step position within 1.5e-3 of the half-width / half-height [8e-4 = 8 mm after 300 steps; typically
+              5e-5], velocity components within 5e-3 [3e-3], angle within 3e-3 rad [1.8e-3], scaled angular velocity within
+              1.5e-2 [8e-3 = 0.02 rad/s, for a few steps when a leg reaches its joint limit one step apart in the two
+              integrations; typically 1e-4]; first leg contact / crash within 1 step [1];
+      landing (closed loop: each integration is steered on its OWN observations, so what differs at touch-down is fed
+              back): both on both legs, asleep, +100; return within 12 [9.8 once -- a slide on a slope --, median 0.2];
+              touch-down within 2 steps [1]; resting place within 0.03 of the half-width = 30 cm [0.015, median 0.002],
+              resting height within 0.003 [0.0009], resting angle within 0.02 rad [0.011]; episode length within 20 steps
+              [6: the sleep timer starts when the last wobble dies]."""
+    from oracle.lander64 import Lander64
+    rng = np.random.RandomState(0)
+    a32, a64 = co.LanderSim(), Lander64()
+    worst = np.zeros(6)
+    for ep in range(30):
+        u = rng.rand(16).astype(np.float32)
+        o32 = a32.reset(u)
+        a64.reset(u)
+        o64 = a64.adopt(a32.debug()[0])
+        assert np.abs(o32[:6] - o64[:6]).max() < 1e-6
+        acts = np.repeat(np.tanh(rng.randn(30, 2) * 1.2), 10, axis=0)
+        d32 = d64 = False
+        c32 = c64 = None
+        for t in range(300):
+            a0, a1 = float(acts[t, 0]), float(acts[t, 1])
+            if not d32:
+                o32, _, d32 = a32.step(a0, a1)
+            if not d64:
+                o64, _, d64 = a64.step(a0, a1)
+            if c32 is None and (o32[6] or o32[7] or d32):
+                c32 = t
+            if c64 is None and (o64[6] or o64[7] or d64):
+                c64 = t
+            if c32 is not None and c64 is not None:
+                break
+            if c32 is None and c64 is None:
+                worst = np.maximum(worst, np.abs(o32[:6] - o64[:6]))
+        assert c32 is not None and c64 is not None and abs(c32 - c64) <= 1, (ep, c32, c64)
+        assert c32 >= 40                                              # a real flight, not a drop
+    assert (worst < np.array([1.5e-3, 1.5e-3, 5e-3, 5e-3, 3e-3, 1.5e-2])).all(), worst
+    gaps = []
+    for ep in range(20):
+        u = rng.rand(16).astype(np.float32)
+        o32 = a32.reset(u)
+        a64.reset(u)
+        o64 = a64.adopt(a32.debug()[0])
+        tot, steps, touch, done, obs = [0.0, 0.0], [0, 0], [None, None], [False, False], [o32, o64.astype(np.float32)]
+        for t in range(700):
+            for k, sim in enumerate((a32, a64)):
+                if not done[k]:
+                    o, r, done[k] = sim.step(*heuristic(obs[k]))
+                    obs[k] = np.asarray(o, dtype=np.float64)
+                    tot[k] += r
+                    steps[k] = t + 1
+                    if touch[k] is None and (o[6] or o[7]):
+                        touch[k] = t
+            if all(done):
+                break
+        assert all(done) and all(o[6] == 1 and o[7] == 1 for o in obs), (ep, obs)
+        assert min(tot) > 200 and abs(tot[0] - tot[1]) < 12.0, (ep, tot)
+        gaps.append(abs(tot[0] - tot[1]))
+        assert abs(touch[0] - touch[1]) <= 2 and abs(steps[0] - steps[1]) <= 20, (ep, touch, steps)
+        assert abs(obs[0][0] - obs[1][0]) < 0.03 and abs(obs[0][1] - obs[1][1]) < 0.003 and abs(obs[0][4] - obs[1][4]) < 0.02, (ep, obs)
+    assert np.median(gaps) < 1.0, gaps

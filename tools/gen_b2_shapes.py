@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates ses_b2_shapes.h (oracle/ and simple-es_amd/csrc/ hold identical copies, like the tanh table): the
+"""Generates simple-es_amd/csrc/ses_b2_shapes.h (the oracle compiles the same file, oracle/Makefile): the
 constant polygon and mass tables of the rigid-body worlds behind LunarLanderContinuous-v2 and BipedalWalker-v3.
 
 gym builds these bodies through pybox2d (Box2D 2.3.0): `polygonShape(vertices=...)` runs b2PolygonShape::Set (convex
@@ -190,7 +190,7 @@ def main():
     out.append("")
     out.append("}  // namespace b2l")
     text = "\n".join(out) + "\n"
-    for rel in ("oracle/ses_b2_shapes.h", "simple-es_amd/csrc/ses_b2_shapes.h"):
+    for rel in ("simple-es_amd/csrc/ses_b2_shapes.h",):
         with open(os.path.join(ROOT, rel), "w") as fh:
             fh.write(text)
     sys.stdout.write(text)
