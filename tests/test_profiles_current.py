@@ -55,3 +55,27 @@ def test_profiles_of_the_newest_round_match_the_shipped_kernels():
             stale.append(f"{name}: profiled {match} = {want[:12]}..., library has {got[:12]}...")
     assert not stale, ("profiles collected on different machine code than the in-tree library -- re-run "
                        "tools/gpu_profile_round.sh and the collect_* summarisers as the last step:\n  " + "\n  ".join(stale))
+
+
+def test_stream_probe_moves_the_env_step_kernels_thirteen_streams():
+    """ses_stream_probe is the ceiling bench.py prints next to the env-step kernel: its machine code must hold exactly the
+    env-step kernel's 7 x 16-byte non-temporal loads and 6 x 16-byte non-temporal stores (a store-back of an unchanged value
+    is something the optimiser drops unless told otherwise -- it did once)."""
+    import shutil
+    import subprocess
+    import tempfile
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    co = kernel_hash._code_object(open(LIB, "rb").read())
+    with tempfile.NamedTemporaryFile(suffix=".co") as f:
+        f.write(co)
+        f.flush()
+        text = subprocess.run([objdump, "-d", "--mcpu=gfx950", f.name], capture_output=True, text=True, timeout=300).stdout
+    counts = {}
+    for frag in ("k_stream_probe13", "k_env_step_cartpole_v4ILb1"):
+        body = re.search(r"<[^>]*" + frag + r"[^>]*>:(.*?)s_endpgm", text, flags=re.S)
+        assert body, frag
+        counts[frag] = (len(re.findall(r"global_load_dwordx4 .* nt", body.group(1))),
+                        len(re.findall(r"global_store_dwordx4 .* nt", body.group(1))))
+    assert counts["k_stream_probe13"] == (7, 6) == counts["k_env_step_cartpole_v4ILb1"], counts
