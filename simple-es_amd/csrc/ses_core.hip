@@ -84,8 +84,8 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     SES_REQUIRE(cfg->eval_ep_num >= 1, "ses_create: eval_ep_num must be >= 1");
     SES_REQUIRE(cfg->max_step >= 1 && cfg->max_step < (1 << 30), "ses_create: max_step must be in [1, 2^30)");
     SES_REQUIRE(cfg->lanes_per_env == 0 || cfg->lanes_per_env == 1 || cfg->lanes_per_env == 2 ||
-                    cfg->lanes_per_env == 4 || cfg->lanes_per_env == 8,
-                "ses_create: lanes_per_env must be 0, 1, 2, 4 or 8");
+                    cfg->lanes_per_env == 4 || cfg->lanes_per_env == 8 || cfg->lanes_per_env == 16,
+                "ses_create: lanes_per_env must be 0, 1, 2, 4, 8 or 16");
     if (cfg->env_id == SES_ENV_CARTPOLE)
         SES_REQUIRE(cfg->num_state == 4 && cfg->num_action == 2 && cfg->discrete_action,
                     "ses_create: CartPole needs num_state=4 num_action=2 discrete_action=1");
@@ -141,6 +141,7 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"gru_sequential", &ses_handle::tune_gru_sequential, 0, 1},
                                  {"rollout_mix", &ses_handle::tune_rollout_mix, 0, 1},
                                  {"rollout_waves8", &ses_handle::tune_rollout_waves8, 1, 1 << 20},
+                                 {"rollout_mix_light", &ses_handle::tune_rollout_mix_light, 0, 16},
                                  {"lander_offspring_per_wave", &ses_handle::tune_lander_per_wave, 0, 4},
                                  {"box2d_lanes_per_env", &ses_handle::tune_box2d_lpe, 0, 64},
                                  {"es_final_max_chunks", &ses_handle::tune_es_final_max_chunks, 0, 1 << 20},
@@ -156,6 +157,8 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                         "ses_set_tuning: lander_offspring_per_wave must be 0, 1, 2 or 4");
             SES_REQUIRE(k.field != &ses_handle::tune_box2d_lpe || (value & (value - 1)) == 0,
                         "ses_set_tuning: box2d_lanes_per_env must be 0 or a power of two up to 64");
+            SES_REQUIRE(k.field != &ses_handle::tune_rollout_mix_light || value == 0 || value == 8 || value == 16,
+                        "ses_set_tuning: rollout_mix_light must be 0, 8 or 16");
             h->*(k.field) = value;
             if (k.field == &ses_handle::tune_comm_p2p_timeout_ms) ses::comm_p2p_set_timeout(h);   // also for a live mailbox
             return SES_OK;

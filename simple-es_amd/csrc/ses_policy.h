@@ -34,6 +34,9 @@ constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm [1,0,3,2]
 constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm [2,3,0,1]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each group of 8
 constexpr int DPP_ROW_ROR8 = 0x128;        // lane i <- lane (i + 8) % 16 inside each row of 16
+constexpr int DPP_ROW_ROR12 = 0x12C;       // row_ror:12: lane i <- lane (i + 4) % 16
+constexpr int DPP_QUAD_00_22 = 0xA0;       // quad_perm [0,0,2,2]: odd lanes <- their even neighbour
+constexpr int DPP_ROW_BCAST1 = 0x151;      // row_newbcast:1: every lane of a row <- lane 1 of the row
 
 // sum over the LPE lanes that share one env; every lane ends with the same bits
 template <int LPE>
@@ -49,7 +52,11 @@ template <int S, int A, int LPE>
 struct MlpSlice {
     static constexpr int U = H / LPE;   // hidden units owned by this lane
     static constexpr int G = U / 4;     // fc2 groups owned by this lane
-    static_assert(U % 4 == 0, "a lane owns whole fc2 groups");
+    // LPE = 16 (U = 2): a lane pair owns one fc2 group; the group's in-order chain passes from the even lane to the odd
+    // one through one DPP move, the tree over the 8 groups runs over the odd lanes of the row, and the action is
+    // broadcast to the row (finish() below).  Same canonical arithmetic, 83 instead of 104 (LPE 8) VALU instructions
+    // per step and wave: for populations that cannot fill the chip otherwise, and as the light wave of the mixed split.
+    static_assert(U % 4 == 0 || U == 2, "a lane owns whole fc2 groups, or a lane pair owns one");
     float w1[U][S];   // times 32 (the tanh table's 1/h), see tanh_index_scaled
     float b1[U];      // times 32
     float w2[A][U];
@@ -109,9 +116,26 @@ struct MlpSlice {
         float a[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) a[u] = tanh_eval(pd.ent[u], pd.frac[u], pd.pre[u]);
+        if constexpr (U == 2) {
+#pragma unroll
+            for (int o = 0; o < A; ++o) {
+                float p = w2[o][0] * a[0];                         // even lane: units 4g, 4g + 1 of the group's chain
+                p = fma_(w2[o][1], a[1], p);
+                float q = dpp_mov<DPP_QUAD_00_22>(p);              // odd lane <- the chain so far
+                q = fma_(w2[o][0], a[0], q);                       // odd lane: units 4g + 2, 4g + 3
+                q = fma_(w2[o][1], a[1], q);
+                // balanced tree over the 8 group sums, which live in the odd lanes 1, 3, ..., 15 of the row: lanes 1 and 3
+                // (and 9, 11) end with the canonical ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7))
+                q = q + dpp_mov<DPP_QUAD_XOR2>(q);
+                q = q + dpp_mov<DPP_ROW_ROR12>(q);
+                q = q + dpp_mov<DPP_ROW_ROR8>(q);
+                logits[o] = dpp_mov<DPP_ROW_BCAST1>(q + b2[o]);    // lane 1 holds the logit: the whole row gets it
+            }
+            return;
+        }
 #pragma unroll
         for (int o = 0; o < A; ++o) {
-            float p[G];
+            float p[G > 0 ? G : 1];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 float acc = w2[o][4 * g] * a[4 * g];

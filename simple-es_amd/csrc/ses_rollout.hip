@@ -193,24 +193,29 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_cartpole_mlp(const float *__r
 // them one per SIMD -- and the remaining envs follow at 4 lanes per env, so every SIMD ends up with one light
 // wave (151 instructions per step) and at most one heavy wave (218).  Results do not depend on the split:
 // every LPE variant evaluates the same canonical arithmetic.
-template <bool FIXED_LENGTH>
+// Round 3: the light wave may also run at 16 lanes per env (LIGHT = 16: 4 envs, 83 instructions per step).  At the
+// benchmark population -- 20 480 envs -- 1024 such waves + 1024 waves at 4 lanes per env put exactly one light and one
+// heavy wave, 20 envs and 243 instructions per step on EVERY SIMD (LIGHT = 8: 264 on three quarters of them, a lone
+// light wave on the rest).  launch_cartpole_mlp picks the split whose busiest SIMD has the least to issue.
+template <bool FIXED_LENGTH, int LIGHT>
 __global__ __launch_bounds__(64) void k_rollout_cartpole_mlp_mix(const float *__restrict__ theta,
                                                                  const float *__restrict__ init,
                                                                  int init_per_offspring, int n_rows, int E, int P,
-                                                                 int max_step, uint32_t obs_mask, int waves8,
+                                                                 int max_step, uint32_t obs_mask, int waves_light,
                                                                  double *__restrict__ ep_return,
                                                                  int32_t *__restrict__ ep_steps)
 {
+    constexpr int EPW = 64 / LIGHT;                    // envs of a light wave
     __shared__ TanhEntry tanh_tab[SES_TANH_N];
     stage_tanh_table(tanh_tab);
     const int n_env = n_rows * E;
-    if ((int)blockIdx.x < waves8) {
-        rollout_cartpole_mlp_body<8, FIXED_LENGTH>(tanh_tab, (long long)blockIdx.x * 64 + threadIdx.x, 0, theta, init,
-                                                   init_per_offspring, n_env < waves8 * 8 ? n_env : waves8 * 8, E, P,
-                                                   max_step, obs_mask, ep_return, ep_steps);
+    if ((int)blockIdx.x < waves_light) {
+        rollout_cartpole_mlp_body<LIGHT, FIXED_LENGTH>(tanh_tab, (long long)blockIdx.x * 64 + threadIdx.x, 0, theta, init,
+                                                       init_per_offspring, n_env < waves_light * EPW ? n_env : waves_light * EPW,
+                                                       E, P, max_step, obs_mask, ep_return, ep_steps);
     } else {
-        rollout_cartpole_mlp_body<4, FIXED_LENGTH>(tanh_tab, (long long)(blockIdx.x - waves8) * 64 + threadIdx.x,
-                                                   waves8 * 8, theta, init, init_per_offspring, n_env, E, P, max_step,
+        rollout_cartpole_mlp_body<4, FIXED_LENGTH>(tanh_tab, (long long)(blockIdx.x - waves_light) * 64 + threadIdx.x,
+                                                   waves_light * EPW, theta, init, init_per_offspring, n_env, E, P, max_step,
                                                    obs_mask, ep_return, ep_steps);
     }
 }
@@ -1025,8 +1030,11 @@ static int pick_lanes_per_env(const ses_handle *h, long long n_env)
 {
     if (h->cfg.lanes_per_env) return h->cfg.lanes_per_env;
     // Measured on MI355X (tools/sweep_lpe.sh): 4 lanes per env wins from 20 480 envs (1280 waves) up to
-    // 327 680 envs; below ~10 000 envs only LPE = 8 still gives every SIMD a wavefront.
-    return n_env * 4 / 64 >= 640 ? 4 : 8;
+    // 327 680 envs; below ~10 000 envs only LPE = 8 still gives every SIMD a wavefront, and while even that leaves the
+    // population within one wave per SIMD (4096 envs) 16 lanes per env make the lone wave's step shorter still
+    // (83 instead of 104 instructions: conf/cartpole.yaml's 480 envs are 500 sequential steps of such a wave).
+    if (n_env * 4 / 64 >= 640) return 4;
+    return n_env <= 4096 ? 16 : 8;
 }
 
 template <int LPE, int BLOCK>
@@ -1114,28 +1122,76 @@ static int lander_offspring_per_wave(const ses_handle *h, int n_rows)
     return n_rows >= 6144 ? 4 : (n_rows >= 1536 ? 2 : 1);
 }
 
+// Which split of the lanes runs a CartPole MLP population of `episodes` envs.  Every split evaluates the same canonical
+// arithmetic; what differs is how much the busiest SIMD has to issue per env step and with how many waves it shares the
+// issue port.  Model (tools/ab_mix_light.py, MI355X): a wave's loop body is 160 / 104 / 84 VALU instructions at 4 / 8 / 16
+// lanes per env; a SIMD that holds k waves issues one of their instructions every 5.0 / 3.45 / 3.1 / 2.95 cycles (k = 1,
+// 2, 3, >= 4: a lone wave waits for its own dependences).  Candidates: the pure splits, and "one light wave per SIMD
+// (8 or 16 lanes per env) + the rest at 4 lanes per env".  Measured against the model at 3072 / 4096 / 5120 offspring x 5
+// episodes: pure 8 (167.7 us) / light 16 + 4 (195.0 us; round 2's light 8 + 4: 213.8) / pure 4 (239.5), all as predicted.
+struct MlpSplit {
+    int light;      // 0: pure split at `lpe` lanes per env; 8 / 16: mixed, light waves at this many lanes per env
+    int lpe;
+};
+
+static MlpSplit choose_cartpole_mlp_split(const ses_handle *h, long long episodes)
+{
+    if (h->cfg.lanes_per_env) return MlpSplit{0, h->cfg.lanes_per_env};
+    if (episodes > 49152) return MlpSplit{0, 4};                       // large populations: 4 lanes per env (tools/sweep_lpe.sh)
+    const int simds = h->tune_rollout_waves8;                           // 1024 = 256 CUs x 4 (knob: the light waves of a mix)
+    auto instr = [](int lpe) { return lpe == 4 ? 160.0 : (lpe == 8 ? 104.0 : 84.0); };
+    auto cadence = [](long long k) { return k <= 1 ? 5.0 : (k == 2 ? 3.45 : (k == 3 ? 3.1 : 2.95)); };
+    MlpSplit best{0, 8};
+    double best_cost = -1.0;
+    auto consider = [&](MlpSplit sp, double cost) {
+        if (best_cost < 0.0 || cost < best_cost) { best_cost = cost; best = sp; }
+    };
+    const bool mix_only = h->tune_rollout_mix_light != 0;
+    if (!mix_only) {
+        for (int lpe : {16, 8, 4}) {
+            const long long k = ceil_div(ceil_div(episodes * lpe, 64), simds);
+            consider(MlpSplit{0, lpe}, k * instr(lpe) * cadence(k));
+        }
+    }
+    if ((h->tune_rollout_mix || mix_only) && episodes > 8192) {
+        for (int light : {16, 8}) {
+            if (mix_only && light != h->tune_rollout_mix_light) continue;
+            const long long envs_light = (long long)simds * (64 / light);
+            if (episodes <= envs_light) continue;
+            const long long kh = ceil_div(ceil_div(episodes - envs_light, 16), simds);
+            consider(MlpSplit{light, 4}, (instr(light) + 160.0 * kh) * cadence(1 + kh));
+        }
+    }
+    return best;
+}
+
 static void launch_cartpole_mlp(const ses_handle *h, const float *theta, const float *init, int per, int n_rows,
                                 int mode, double *epr, int32_t *ep_steps)
 {
     const long long episodes = (long long)n_rows * h->cfg.eval_ep_num;
-    if (h->cfg.lanes_per_env == 0 && h->tune_rollout_mix && episodes > 8192 && episodes <= 49152) {
-        const int waves8_knob = h->tune_rollout_waves8;                // default 1024: one light wave per SIMD (256 CUs x 4)
-        const int waves8 = (long long)waves8_knob * 8 < episodes ? waves8_knob : (int)(episodes / 8);
-        const int waves4 = ceil_div(episodes - 8ll * waves8, 16);
-        if (mode == SES_MODE_FIXED_LENGTH)
-            hipLaunchKernelGGL((k_rollout_cartpole_mlp_mix<true>), dim3(waves8 + waves4), dim3(64), 0, h->stream, theta,
-                               init, per, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, waves8, epr,
-                               ep_steps);
-        else
-            hipLaunchKernelGGL((k_rollout_cartpole_mlp_mix<false>), dim3(waves8 + waves4), dim3(64), 0, h->stream, theta,
-                               init, per, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, waves8, epr,
-                               ep_steps);
+    const MlpSplit sp = choose_cartpole_mlp_split(h, episodes);
+    if (sp.light) {
+        // one light wave per SIMD (the dispatcher deals the first workgroups one per SIMD) + the rest at 4 lanes per env
+        const int epw = 64 / sp.light, knob = h->tune_rollout_waves8;
+        const int waves_light = (long long)knob * epw < episodes ? knob : (int)(episodes / epw);
+        const int waves4 = ceil_div(episodes - (long long)epw * waves_light, 16);
+        const dim3 grid(waves_light + waves4), block(64);
+#define SES_MIX_LAUNCH(FIXED_, LIGHT_)                                                                                   \
+    hipLaunchKernelGGL((k_rollout_cartpole_mlp_mix<FIXED_, LIGHT_>), grid, block, 0, h->stream, theta, init, per, n_rows,   \
+                       h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, waves_light, epr, ep_steps)
+        if (mode == SES_MODE_FIXED_LENGTH) {
+            if (sp.light == 16) SES_MIX_LAUNCH(true, 16); else SES_MIX_LAUNCH(true, 8);
+        } else {
+            if (sp.light == 16) SES_MIX_LAUNCH(false, 16); else SES_MIX_LAUNCH(false, 8);
+        }
+#undef SES_MIX_LAUNCH
         return;
     }
-    switch (pick_lanes_per_env(h, episodes)) {
+    switch (sp.lpe) {
         case 1: launch_rollout<1>(h, theta, init, per, n_rows, mode, epr, ep_steps); break;
         case 2: launch_rollout<2>(h, theta, init, per, n_rows, mode, epr, ep_steps); break;
         case 4: launch_rollout<4>(h, theta, init, per, n_rows, mode, epr, ep_steps); break;
+        case 16: launch_rollout<16>(h, theta, init, per, n_rows, mode, epr, ep_steps); break;
         default: launch_rollout<8>(h, theta, init, per, n_rows, mode, epr, ep_steps); break;
     }
 }
@@ -1151,7 +1207,7 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
     SES_REQUIRE(h && theta && init && fitness, "ses_rollout: null argument");
     SES_REQUIRE(n_rows >= 1, "ses_rollout: n_rows must be >= 1");
     SES_REQUIRE(mode == SES_MODE_EPISODIC || mode == SES_MODE_FIXED_LENGTH, "ses_rollout: bad mode %d", mode);
-    SES_REQUIRE((long long)n_rows * h->cfg.eval_ep_num * 8 < (1ll << 31), "ses_rollout: shard too large");
+    SES_REQUIRE((long long)n_rows * h->cfg.eval_ep_num * 16 < (1ll << 31), "ses_rollout: shard too large");
     SES_REQUIRE(h->cfg.env_id == SES_ENV_CARTPOLE || h->cfg.env_id == SES_ENV_SIMPLE_SPREAD ||
                     h->cfg.env_id == SES_ENV_LUNARLANDER || h->cfg.env_id == SES_ENV_BIPEDALWALKER,
                 "ses_rollout: handle has no env");
