@@ -510,6 +510,10 @@ __device__ __forceinline__ void gru_lockstep_multi_batch(const TanhEntry *tanh_t
         for (int o = 0; o < A; ++o) logits[o] = 0.0f;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+            // an offspring all of whose episodes are over needs no policy step any more (wave-uniform test): in the last
+            // two thirds of a C3 rollout most waves carry ONE offspring with a long episode, and the other one's weight
+            // re-read + GRU step was a tenth of their step
+            if (__ballot(alive & owner_valid & (gl == g)) == 0ull) continue;
             const int row_g = row0 + g < n_rows ? row0 + g : n_rows - 1;
             GruLockstep<S, A> net;
             net.template load<false>(theta + (size_t)row_g * P, lane, lds[g]);
@@ -1119,7 +1123,9 @@ static bool gru_sequential(const ses_handle *h) { return h->tune_gru_sequential 
 static int lander_offspring_per_wave(const ses_handle *h, int n_rows)
 {
     if (h->tune_lander_per_wave) return h->tune_lander_per_wave;
-    return n_rows >= 6144 ? 4 : (n_rows >= 1536 ? 2 : 1);
+    // round 3: a finished offspring's GRU step is skipped, which makes four offspring per wave the better choice from
+    // ~3000 offspring on (C3, 4096 x 5 x <= 300: 40.6 ms at two per wave, 37.4 at four, same box; tools/c3_breakdown.py)
+    return n_rows >= 3072 ? 4 : (n_rows >= 1536 ? 2 : 1);
 }
 
 // Which split of the lanes runs a CartPole MLP population of `episodes` envs.  Every split evaluates the same canonical
