@@ -182,6 +182,7 @@ int ses_destroy(ses_handle *h)
     if (h->ep_return) (void)hipFree(h->ep_return);
     if (h->ep_steps) (void)hipFree(h->ep_steps);
     if (h->red_scratch) (void)hipFree(h->red_scratch);
+    if (h->gen_init) (void)hipFree(h->gen_init);
     delete h;
     return SES_OK;
 }

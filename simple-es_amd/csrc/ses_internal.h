@@ -18,6 +18,8 @@ struct ses_handle {
     size_t ep_cap;       // capacity in episodes
     void *red_scratch;   // rank keys (u64[n]) followed by es_update partial sums
     size_t red_cap;      // bytes
+    float *gen_init;     // ses_run_generations: the env resets of a chunk of generations, drawn in one launch
+    size_t gen_init_cap; // floats
     // multi-GPU (ses_comm.hip): RCCL communicator of this rank, null until ses_comm_init
     void *comm;
     int comm_rank, comm_world;
@@ -72,5 +74,7 @@ int ensure_episode_scratch(ses_handle *h, size_t episodes);
 int ensure_reduce_scratch(ses_handle *h, size_t bytes);
 int comm_release(ses_handle *h);
 void comm_p2p_set_timeout(ses_handle *h);
+int init_states_uniform_gens(ses_handle *h, uint64_t seed, uint64_t gen0, int gens, int64_t first_row, int32_t n_rows,
+                             int32_t shared, int32_t width, float lo, float hi, float *out);
 
 }  // namespace ses

@@ -76,12 +76,16 @@ __global__ __launch_bounds__(256) void k_init_states_uniform(uint64_t seed, uint
                                                              int n_rows, int E, int S, int shared, float lo,
                                                              float span, float *__restrict__ out)
 {
+    // blockIdx.y: consecutive generations (ses_run_generations draws the resets of a whole chunk of generations in one
+    // launch: generation gen + y goes to out + y * n_rows * E * S)
     const int sq = (S + 3) / 4;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)n_rows * E * sq) return;
     const int q = (int)(t % sq);
     const int e = (int)((t / sq) % E);
     const int i = (int)(t / ((long long)sq * E));
+    gen += blockIdx.y;
+    out += (size_t)blockIdx.y * n_rows * E * S;
     const uint4 r = philox_words(seed, TAG_ENV_INIT, gen, shared ? 0u : (uint32_t)(first_row + i), (uint32_t)(e * 8 + q));
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
     for (int l = 0; l < 4 && 4 * q + l < S; ++l)
@@ -556,6 +560,27 @@ int ses_init_states_uniform(ses_handle *h, uint64_t seed, uint64_t gen, int64_t 
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;
 }
+
+}  // extern "C"
+
+namespace ses {
+// the resets of `gens` consecutive generations in one launch: out[g] = what ses_init_states_uniform(gen0 + g) writes
+int init_states_uniform_gens(ses_handle *h, uint64_t seed, uint64_t gen0, int gens, int64_t first_row, int32_t n_rows,
+                             int32_t shared, int32_t width, float lo, float hi, float *out)
+{
+    SES_REQUIRE(h && out && gens >= 1 && gens <= 65535 && n_rows >= 1 && first_row >= 0, "init_states_uniform_gens: bad argument");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    const int S = width, E = h->cfg.eval_ep_num;
+    SES_REQUIRE(E * 8 < (1 << 30) && S >= 1 && S <= 32, "init_states_uniform_gens: shape");
+    const long long threads = (long long)n_rows * E * ((S + 3) / 4);
+    hipLaunchKernelGGL(k_init_states_uniform, dim3(ceil_div(threads, 256), gens), dim3(256), 0, h->stream, seed, gen0,
+                       (long long)first_row, n_rows, E, S, shared, lo, hi - lo, out);
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+}  // namespace ses
+
+extern "C" {
 
 int ses_rank_center(ses_handle *h, const float *fitness, int32_t n, int32_t *rank, double *weights, float *best)
 {

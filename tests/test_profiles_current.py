@@ -67,11 +67,14 @@ def test_stream_probe_moves_the_env_step_kernels_thirteen_streams():
     objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump):
         pytest.skip("llvm-objdump not available")
-    co = kernel_hash._code_object(open(LIB, "rb").read())
-    with tempfile.NamedTemporaryFile(suffix=".co") as f:
-        f.write(co)
-        f.flush()
-        text = subprocess.run([objdump, "-d", "--mcpu=gfx950", f.name], capture_output=True, text=True, timeout=300).stdout
+    text = ""
+    for co in kernel_hash._code_objects(open(LIB, "rb").read()):
+        if b"k_stream_probe13" not in co:
+            continue
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            text += subprocess.run([objdump, "-d", "--mcpu=gfx950", f.name], capture_output=True, text=True, timeout=300).stdout
     counts = {}
     for frag in ("k_stream_probe13", "k_env_step_cartpole_v4ILb1"):
         body = re.search(r"<[^>]*" + frag + r"[^>]*>:(.*?)s_endpgm", text, flags=re.S)

@@ -33,43 +33,55 @@ def _sections(elf):
     return secs
 
 
-def _code_object(lib_bytes, arch="gfx950"):
+def _code_objects(lib_bytes, arch="gfx950"):
+    """Every gfx950 code object of the library: one clang offload bundle per translation unit (csrc/build.sh compiles the
+    units separately, the linker concatenates their .hip_fatbin contributions)."""
     secs = _sections(lib_bytes)
     fat = next(s for s in secs if s["name"] == ".hip_fatbin")
     blob = lib_bytes[fat["off"]:fat["off"] + fat["size"]]
-    pos = blob.find(BUNDLE_MAGIC)
-    if pos < 0 and blob[:4] == b"CCOB":                      # compressed bundle: header, then one zlib / zstd stream
+    if blob.find(BUNDLE_MAGIC) < 0 and blob[:4] == b"CCOB":   # compressed bundle: header, then one zlib / zstd stream
         raise RuntimeError("compressed offload bundle: rebuild with --no-offload-compress or hash with llvm tools")
+    out, pos = [], blob.find(BUNDLE_MAGIC)
     assert pos >= 0, "no clang offload bundle in .hip_fatbin"
-    blob = blob[pos:]
-    n, = struct.unpack_from("<Q", blob, len(BUNDLE_MAGIC))
-    p = len(BUNDLE_MAGIC) + 8
-    for _ in range(n):
-        off, size, tlen = struct.unpack_from("<QQQ", blob, p)
-        triple = blob[p + 24:p + 24 + tlen].decode()
-        p += 24 + tlen
-        if arch in triple and size:
-            return blob[off:off + size]
-    raise RuntimeError(f"no {arch} code object in the bundle")
+    while pos >= 0:
+        nxt = blob.find(BUNDLE_MAGIC, pos + len(BUNDLE_MAGIC))
+        b = blob[pos:nxt if nxt >= 0 else len(blob)]
+        n, = struct.unpack_from("<Q", b, len(BUNDLE_MAGIC))
+        p = len(BUNDLE_MAGIC) + 8
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from("<QQQ", b, p)
+            triple = b[p + 24:p + 24 + tlen].decode()
+            p += 24 + tlen
+            if arch in triple and size:
+                out.append(b[off:off + size])
+        pos = nxt
+    if not out:
+        raise RuntimeError(f"no {arch} code object in the bundle")
+    return out
+
+
+def _code_object(lib_bytes, arch="gfx950"):
+    """the first gfx950 code object (kept for callers that disassemble one unit); see _code_objects"""
+    return _code_objects(lib_bytes, arch)[0]
 
 
 def kernel_symbols(lib_path, fragment):
-    """{mangled name: machine code bytes} of the FUNC symbols of the gfx950 code object whose name contains fragment"""
-    co = _code_object(open(lib_path, "rb").read())
-    secs = _sections(co)
-    symtab = next(s for s in secs if s["name"] == ".symtab")
-    strtab = secs[symtab["link"]]
+    """{mangled name: machine code bytes} of the FUNC symbols of the gfx950 code objects whose name contains fragment"""
     out = {}
-    for i in range(symtab["size"] // 24):
-        name_off, info, _other, shndx, value, size = struct.unpack_from("<IBBHQQ", co, symtab["off"] + 24 * i)
-        if (info & 0xF) != 2 or size == 0 or shndx == 0 or shndx >= len(secs):       # STT_FUNC only
-            continue
-        end = co.index(b"\0", strtab["off"] + name_off)
-        name = co[strtab["off"] + name_off:end].decode()
-        if fragment in name:
-            sec = secs[shndx]
-            start = sec["off"] + (value - sec["addr"])
-            out[name] = co[start:start + size]
+    for co in _code_objects(open(lib_path, "rb").read()):
+        secs = _sections(co)
+        symtab = next(s for s in secs if s["name"] == ".symtab")
+        strtab = secs[symtab["link"]]
+        for i in range(symtab["size"] // 24):
+            name_off, info, _other, shndx, value, size = struct.unpack_from("<IBBHQQ", co, symtab["off"] + 24 * i)
+            if (info & 0xF) != 2 or size == 0 or shndx == 0 or shndx >= len(secs):       # STT_FUNC only
+                continue
+            end = co.index(b"\0", strtab["off"] + name_off)
+            name = co[strtab["off"] + name_off:end].decode()
+            if fragment in name:
+                sec = secs[shndx]
+                start = sec["off"] + (value - sec["addr"])
+                out[name] = co[start:start + size]
     return out
 
 
