@@ -443,6 +443,11 @@ def run_rank(args):
         roll_ms = statistics.median(samples)
         n_local = pop.theta.shape[0]
         result["rollout_kernel"] = {"ms": roll_ms, "env_steps_per_s_one_gpu": n_local * E * T / (roll_ms * 1e-3),
+                                    "includes": "the fused rollout kernel + the episode-mean kernel (one ses_rollout call)",
+                                    "split": ("1024 waves x 4 envs at 16 lanes per env + 1024 waves x 16 envs at 4 lanes per env: one "
+                                              "light and one heavy wave, 20 envs, 244 VALU instructions per step on every SIMD "
+                                              "(chosen by the library's issue-cost model, csrc/ses_rollout.hip)"
+                                              if (n_local * E == 20480 and not args.gru) else "chosen by the library"),
                                     "bound": "valu-issue/latency (state and weights in VGPRs, no HBM traffic in the loop)",
                                     "mfma": "not used at eval_ep_num < 12: fp32 MFMA runs at the VALU rate and a 16-column "
                                             "tile would be 5/16 full (profiles/r01_mfma_vs_valu_gru.txt)"}
@@ -515,8 +520,27 @@ def run_rank(args):
                 _, _, st3 = c3.rollout(th, ini, want_episodes=True)
                 n3 = int(st3.sum().item())
                 ms3 = statistics.median(ts)
+                # the same population with the main-engine output biased on (fc2 bias of output 0 + 1.5): policies that
+                # fly instead of dropping -- what a trained population looks like to the kernel (long episodes)
+                thl = th.clone()
+                thl[:, c3.P - 4] += 1.5
+                c3.rollout(thl, ini, fitness=fit3)
+                torch.cuda.synchronize()
+                tl = []
+                for _ in range(3):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    c3.rollout(thl, ini, fitness=fit3)
+                    e1.record()
+                    e1.synchronize()
+                    tl.append(e0.elapsed_time(e1))
+                _, _, stl = c3.rollout(thl, ini, want_episodes=True)
+                nl, msl = int(stl.sum().item()), statistics.median(tl)
                 result["c3_lunarlander_pomdp_gru_4096"] = {
                     "rollout_ms": ms3, "env_steps": n3, "env_steps_per_s": n3 / (ms3 * 1e-3), "mean_episode_steps": n3 / (4096 * 5),
+                    "flying_policies": {"rollout_ms": msl, "env_steps": nl, "env_steps_per_s": nl / (msl * 1e-3),
+                                        "mean_episode_steps": nl / (4096 * 5),
+                                        "note": "same population, main-engine bias + 1.5: long flights, what trained policies cost"},
                     "env": "gym's lunar_lander.py restated on a Box2D-style world: 3 bodies, 2 revolute joints, 180 velocity + "
                            "<= 60 position iterations per step, time-of-impact sub-stepping against the terrain (parity with gym / Box2D unpinned; GPU == CPU build bit for bit)",
                     "bound": "valu issue + the latency of the sequential solver (profiles: *_sq_c3_lander.json)"}

@@ -1,6 +1,5 @@
 """BipedalWalker-v3 on the CPU (oracle/ses_walker_env.h over the Box2D-style world of oracle/ses_b2.h): behavioural
 checks -- gym and Box2D are not here to compare with (parity unpinned, see the headers)."""
-import filecmp
 import os
 
 import numpy as np
@@ -10,9 +9,10 @@ from oracle import c_oracle as co
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_walker_header_is_one_text_in_oracle_and_product():
-    assert filecmp.cmp(os.path.join(ROOT, "oracle", "ses_walker_env.h"),
-                       os.path.join(ROOT, "simple-es_amd", "csrc", "ses_walker_env.h"), shallow=False)
+def test_walker_header_exists_once():
+    # one text, compiled for gfx950 by the product and for the host by the oracle (oracle/Makefile: -I simple-es_amd/csrc)
+    assert os.path.exists(os.path.join(ROOT, "simple-es_amd", "csrc", "ses_walker_env.h"))
+    assert not os.path.exists(os.path.join(ROOT, "oracle", "ses_walker_env.h"))
 
 
 def test_terrain_is_gyms_random_walk():
