@@ -144,6 +144,11 @@ int ses_perturb_host_noise(ses_handle *h, const float *parents, const int32_t *p
  * seeds its env: initial states are an explicit input of this library. */
 int ses_init_states_uniform(ses_handle *h, uint64_t seed, uint64_t gen, int64_t first_row, int32_t n_rows,
                             int32_t shared, int32_t width, float lo, float hi, float *out);
+/* The same for `gens` consecutive generations in ONE launch: out[g, n_rows, E, width] = what ses_init_states_uniform writes
+ * for generation gen0 + g.  The resets depend on (seed, generation, row) only, so a generation loop draws them a chunk
+ * ahead instead of once per generation (ESLoop.rollout, ses_run_generations). */
+int ses_init_states_uniform_gens(ses_handle *h, uint64_t seed, uint64_t gen0, int32_t gens, int64_t first_row,
+                                 int32_t n_rows, int32_t shared, int32_t width, float lo, float hi, float *out);
 
 /* ---- K2: population-batched policy forward (networks/neural_network.py:20-36) ------------- */
 /* n independent (row, observation[, hidden]) triples.  hidden: float32[n,32] in/out, NULL for MLP.

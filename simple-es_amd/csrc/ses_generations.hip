@@ -49,7 +49,7 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
             SES_HIP_TRY(hipMalloc(&h->gen_init, slice * (size_t)k * sizeof(float)));
             h->gen_init_cap = slice * (size_t)k;
         }
-        rc = init_states_uniform_gens(h, st->env_seed, st->pop_gen, k, 0, st->shared_init ? 1 : n, st->shared_init, st->init_width,
+        rc = ses_init_states_uniform_gens(h, st->env_seed, st->pop_gen, k, 0, st->shared_init ? 1 : n, st->shared_init, st->init_width,
                                       st->init_lo, st->init_hi, h->gen_init);
     }
     for (int g = 0; g < k && rc == SES_OK; ++g) {

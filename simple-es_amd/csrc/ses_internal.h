@@ -74,7 +74,6 @@ int ensure_episode_scratch(ses_handle *h, size_t episodes);
 int ensure_reduce_scratch(ses_handle *h, size_t bytes);
 int comm_release(ses_handle *h);
 void comm_p2p_set_timeout(ses_handle *h);
-int init_states_uniform_gens(ses_handle *h, uint64_t seed, uint64_t gen0, int gens, int64_t first_row, int32_t n_rows,
-                             int32_t shared, int32_t width, float lo, float hi, float *out);
+
 
 }  // namespace ses

@@ -561,26 +561,20 @@ int ses_init_states_uniform(ses_handle *h, uint64_t seed, uint64_t gen, int64_t 
     return SES_OK;
 }
 
-}  // extern "C"
-
-namespace ses {
-// the resets of `gens` consecutive generations in one launch: out[g] = what ses_init_states_uniform(gen0 + g) writes
-int init_states_uniform_gens(ses_handle *h, uint64_t seed, uint64_t gen0, int gens, int64_t first_row, int32_t n_rows,
-                             int32_t shared, int32_t width, float lo, float hi, float *out)
+int ses_init_states_uniform_gens(ses_handle *h, uint64_t seed, uint64_t gen0, int32_t gens, int64_t first_row, int32_t n_rows,
+                                 int32_t shared, int32_t width, float lo, float hi, float *out)
 {
-    SES_REQUIRE(h && out && gens >= 1 && gens <= 65535 && n_rows >= 1 && first_row >= 0, "init_states_uniform_gens: bad argument");
+    SES_REQUIRE(h && out, "ses_init_states_uniform_gens: null argument");
+    SES_REQUIRE(gens >= 1 && gens <= 65535 && n_rows >= 1 && first_row >= 0, "ses_init_states_uniform_gens: bad range");
     SES_HIP_TRY(hipSetDevice(h->cfg.device));
     const int S = width, E = h->cfg.eval_ep_num;
-    SES_REQUIRE(E * 8 < (1 << 30) && S >= 1 && S <= 32, "init_states_uniform_gens: shape");
+    SES_REQUIRE(E * 8 < (1 << 30) && S >= 1 && S <= 32, "ses_init_states_uniform_gens: shape");
     const long long threads = (long long)n_rows * E * ((S + 3) / 4);
     hipLaunchKernelGGL(k_init_states_uniform, dim3(ceil_div(threads, 256), gens), dim3(256), 0, h->stream, seed, gen0,
                        (long long)first_row, n_rows, E, S, shared, lo, hi - lo, out);
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;
 }
-}  // namespace ses
-
-extern "C" {
 
 int ses_rank_center(ses_handle *h, const float *fitness, int32_t n, int32_t *rank, double *weights, float *best)
 {

@@ -163,10 +163,7 @@ class ESLoop(BaseESLoop):
         self._metrics = None
         self._stamps = None
         self._ev_k = 0
-        self._prefetched = None     # ((generation, first row, rows), init states, event) drawn ahead on the side stream
-        self._side = None
-        self._side_dev = None
-        self._main = None                       # the launch stream, looked up once
+        self._init_chunk = None     # ((first row, rows, shared), first generation, resets[gens, rows, E, W]) drawn ahead
 
         # logs/<env>/<timestamp>[_k]: the reference's makedirs (loop.py:40-47) raises when two loops start in the same
         # second; here the second one gets a suffix instead of silently sharing the directory.  Only rank 0 writes.
@@ -199,43 +196,30 @@ class ESLoop(BaseESLoop):
         self._guarded = False
 
     def _init_states(self, gen, shard):
+        """The env resets of generation `gen` for this rank's rows.  They depend on (env seed, generation, row) only, so they
+        are drawn a chunk of generations ahead in ONE launch (ses_init_states_uniform_gens) and handed out as views: no
+        reset kernel between one generation's last kernel and the next rollout.  (Round 2 drew generation g + 1 on a side
+        stream during rollout g; side stream and main stream share a hardware queue, and the side kernel + its event sat
+        between two kernels of the tail: ~5 us per generation, as much as it saved.)"""
+        key = (shard.first, shard.n_local, self.shared_init)
+        c = self._init_chunk
+        if c is None or c[0] != key or not c[1] <= gen < c[1] + c[2].shape[0]:
+            rows = 1 if self.shared_init else max(shard.n_local, 1)
+            per_gen = rows * self.dev.E * self.dev.init_dim * 4
+            gens = max(1, min(64, (32 << 20) // per_gen))
+            buf = self.dev.init_states_uniform_gens(self.seed_env, gen, gens, 0 if self.shared_init else shard.first, rows,
+                                                    shared=self.shared_init)
+            c = self._init_chunk = (key, gen, buf)
+        init = c[2][gen - c[1]]
         if self.shared_init:                       # common random numbers: every offspring sees the same resets
-            return self.dev.init_states_uniform(self.seed_env, gen, 0, 1, shared=True)[0]
-        init = self.dev.init_states_uniform(self.seed_env, gen, shard.first, max(shard.n_local, 1))   # reference: independent resets
-        return init[: shard.n_local].contiguous() if shard.n_local != init.shape[0] else init
+            return init[0]
+        return init[: shard.n_local] if shard.n_local != init.shape[0] else init
 
     # the rollout phase of one generation: Population -> float32[N] fitness (identical on every rank)
     def rollout(self, population):
         shard = population.shard
-        # The resets of a generation depend on (env seed, generation counter) only, so those of generation g + 1 are
-        # drawn on a side stream while rollout g runs (a 4 us kernel that would otherwise sit between the last kernel of
-        # one generation and the rollout of the next); the launch stream waits for the side stream's event, long done.
-        pre = self._prefetched
-        if self._main is None:
-            self._main = torch.cuda.current_stream(self.dev.device)           # the loop's launch stream, looked up once (8 us a call)
-        if pre is not None and pre[0] == (population.gen, shard.first, shard.n_local):
-            self._main.wait_event(pre[2])
-            init = pre[1]
-        else:
-            init = self._init_states(population.gen, shard)
+        init = self._init_states(population.gen, shard)
         local = self.dev.rollout(population.theta, init, mode=self.mode) if shard.n_local else self.dev.empty(0)
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.dev.device)
-            self._side_dev = HipES(self.env.name, self.network.num_state, self.network.num_action,
-                                   self.network.discrete_action, self.network.use_gru, pomdp=self.env.pomdp,
-                                   max_step=self.env.horizon, eval_ep_num=self.eval_ep_num,
-                                   n_agents=getattr(self.env, "n_agents", 1), stream=self._side)
-        done = torch.cuda.Event()
-        with torch.cuda.stream(self._side):                                   # allocation and launch on the side stream
-            if self.shared_init:
-                nxt = self._side_dev.init_states_uniform(self.seed_env, population.gen + 1, 0, 1, shared=True)[0]
-            else:
-                nxt = self._side_dev.init_states_uniform(self.seed_env, population.gen + 1, shard.first, max(shard.n_local, 1))
-                if shard.n_local != nxt.shape[0]:
-                    nxt = nxt[: shard.n_local].contiguous()
-            done.record()
-        nxt.record_stream(self._main)                                         # consumed by the next rollout on the launch stream
-        self._prefetched = ((population.gen + 1, shard.first, shard.n_local), nxt, done)
         return shard.allgather_fitness(local, dev=self.dev)
 
     def generation(self, offsprings):
@@ -361,7 +345,7 @@ class ESLoop(BaseESLoop):
                         del self.history[snap[2]:]
                         self.ep5_rewards.clear()
                         self.ep5_rewards.extend(snap[3])
-                        self._prefetched, self._prev_tail = None, 0
+                        self._prev_tail = 0
                         continue
                     snap = (ep_num, strategy.snapshot(offsprings), len(self.history), list(self.ep5_rewards))
                 if checkpoint and rank0:

@@ -80,6 +80,7 @@ SIGNATURES = {
     "ses_noise": [_vp, _u64, _u64, _i64, _i32, _vp],
     "ses_perturb_host_noise": [_vp, _vp, _vp, _vp, _f64, _i32, _vp, _vp],
     "ses_init_states_uniform": [_vp, _u64, _u64, _i64, _i32, _i32, _i32, _f32, _f32, _vp],
+    "ses_init_states_uniform_gens": [_vp, _u64, _u64, _i32, _i64, _i32, _i32, _i32, _f32, _f32, _vp],
     "ses_policy_forward": [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "ses_env_step": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ses_env_state_bytes": [_vp],

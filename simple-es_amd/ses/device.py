@@ -297,6 +297,16 @@ class HipES:
               "ses_init_states_uniform")
         return out
 
+    def init_states_uniform_gens(self, seed, gen0, gens, first_row, n_rows, shared=False, out=None):
+        """The resets of `gens` consecutive generations in one launch: float32[gens, n_rows, E, init_dim]."""
+        lo, hi = self.init_range
+        out = (self.empty(gens, n_rows, self.E, self.init_dim) if out is None else
+               self._chk(out, "out", torch.float32, (gens, n_rows, self.E, self.init_dim)))
+        check(self._lib.ses_init_states_uniform_gens(self._h, int(seed), int(gen0), int(gens), int(first_row), int(n_rows),
+                                                     int(bool(shared)), int(self.init_dim), float(lo), float(hi), _ptr(out)),
+              "ses_init_states_uniform_gens")
+        return out
+
     # -- K2 / K3 ------------------------------------------------------------------------------
     def policy_forward(self, theta, obs, hidden=None):
         n = obs.shape[0]
