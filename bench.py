@@ -432,18 +432,23 @@ def run_rank(args):
         pop = job.pop
         init = es.init_states_uniform(0, 0, 0, 1, shared=True)[0]
         samples = []
+        fit_buf = es.empty(pop.theta.shape[0])
+        for _ in range(20):
+            es.rollout(pop.theta, init, mode=job.loop.mode, fitness=fit_buf)
         torch.cuda.synchronize()
-        for rep in range(9):                                   # median of 9 rollout launches
+        for rep in range(9):                                   # median of 9 batches of 5 back-to-back ses_rollout calls
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             ev[0].record()
-            es.rollout(pop.theta, init, mode=job.loop.mode)
+            for _ in range(5):
+                es.rollout(pop.theta, init, mode=job.loop.mode, fitness=fit_buf)
             ev[1].record()
             ev[1].synchronize()
-            samples.append(ev[0].elapsed_time(ev[1]))
+            samples.append(ev[0].elapsed_time(ev[1]) / 5)
         roll_ms = statistics.median(samples)
         n_local = pop.theta.shape[0]
         result["rollout_kernel"] = {"ms": roll_ms, "env_steps_per_s_one_gpu": n_local * E * T / (roll_ms * 1e-3),
-                                    "includes": "the fused rollout kernel + the episode-mean kernel (one ses_rollout call)",
+                                    "includes": "the fused rollout kernel + the episode-mean kernel (one ses_rollout call; ~4.4 us of it is the mean kernel, "
+                                                "profiles/*_kernel_stats.csv has the rollout kernel alone)",
                                     "split": ("1024 waves x 4 envs at 16 lanes per env + 1024 waves x 16 envs at 4 lanes per env: one "
                                               "light and one heavy wave, 20 envs, 244 VALU instructions per step on every SIMD "
                                               "(chosen by the library's issue-cost model, csrc/ses_rollout.hip)"

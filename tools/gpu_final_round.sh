@@ -1,0 +1,48 @@
+#!/bin/bash
+# The evidence round of a build (one gpurun call, ~8 minutes): GPU tests, every counter / trace pass of tools/gpu_profile_round.sh
+# plus the MFMA and Box2D MLP passes, the summaries (with the kernels' machine-code hashes) written to profiles/ AND staged
+# under gpurun_out/final/ (gpurun merges only gpurun_out/ back), fuzz at depth, the env-step A/B of this box, the bench
+# lines, loop timings.   usage: tools/gpu_final_round.sh [round tag = r03] [fuzz seconds per process = 240]
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+TAG=${1:-r03}
+FUZZ=${2:-240}
+OUT=gpurun_out/final
+rm -rf $OUT; mkdir -p $OUT
+python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/${TAG}_pytest_gpu.log
+bash tools/gpu_profile_round.sh > $OUT/profile_round.txt 2>&1; tail -3 $OUT/profile_round.txt | cut -c1-200
+bash tools/prof_mfma.sh > gpurun_out/sq_mfma.txt 2>&1
+bash tools/prof_sq_box2d.sh 4096 > gpurun_out/sqb2.txt 2>&1
+python tools/collect_pmc.py $TAG
+python tools/collect_sq.py $TAG rollout k_rollout_cartpole_mlp gpurun_out/sq_mlp/sq_1 gpurun_out/sq_mlp/sq_2
+python tools/collect_sq.py $TAG gru_lockstep k_rollout_gru_lockstep gpurun_out/sq_gru/sq_1 gpurun_out/sq_gru/sq_2
+python tools/collect_sq.py $TAG c3_lander LanderLs gpurun_out/sqc3_1 gpurun_out/sqc3_2
+python tools/collect_sq.py $TAG gru_mfma k_rollout_gru_mfma gpurun_out/mf_1 gpurun_out/mf_2
+python tools/collect_sq.py $TAG box2d_mlp k_rollout_box2d_mlp gpurun_out/sqb2_1 gpurun_out/sqb2_2
+cp profiles/${TAG}_pmc_env_step.json profiles/${TAG}_sq_*.json $OUT/
+cp gpurun_out/kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
+tail -1 gpurun_out/prof_kt_bench.log > $OUT/${TAG}_bench_profiled.json
+cp gpurun_out/pmc_stdout.txt $OUT/${TAG}_pmc_stdout.txt
+cp gpurun_out/configs.jsonl $OUT/${TAG}_configs.jsonl
+python tools/timeline_gaps.py $(find gpurun_out/prof_kt -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_generation_timeline.txt 2>&1
+rm -f gpurun_out/fuzz_[0-9]*.txt
+bash tools/fuzz_round.sh $FUZZ 300 > $OUT/${TAG}_fuzz_parity.txt 2>&1; tail -1 $OUT/${TAG}_fuzz_parity.txt | cut -c1-300
+grep -h MISMATCH gpurun_out/fuzz_[0-9]*.txt | head -5
+tools/envstep_ab 24 15 20 200 > $OUT/${TAG}_envstep_ab_final_box.txt 2>&1; head -3 $OUT/${TAG}_envstep_ab_final_box.txt
+python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+python bench.py --gru --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_gru.json 2>> $OUT/bench.err
+python bench.py --gru --eval-ep-num 16 --no-extras --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_gru16.json 2>> $OUT/bench.err
+python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_flags.json 2>> $OUT/bench.err
+for cfg in cartpole_openai.yaml cartpole.yaml cartpole_pomdp_gru.yaml simplespread.yaml lunarlander_openai.yaml; do
+  python tools/time_loop.py $cfg 2>&1 | tail -1
+done > $OUT/${TAG}_time_loop.txt
+python tools/time_loop.py lunarlander.yaml 0 300 2>&1 | tail -1 >> $OUT/${TAG}_time_loop.txt
+python tools/time_loop.py bipedalwalker.yaml 0 60 2>&1 | tail -1 >> $OUT/${TAG}_time_loop.txt
+cat $OUT/${TAG}_time_loop.txt
+python tools/c3_breakdown.py > $OUT/${TAG}_c3_breakdown.txt 2>&1
+python tools/lander_step_cost.py > $OUT/${TAG}_lander_step_cost.txt 2>&1
+python tools/time_tail.py > $OUT/${TAG}_time_tail.txt 2>&1
+# gpurun copies gpurun_out/ back only below 64 MiB: the raw rocprofv3 directories stay on the box
+find gpurun_out -mindepth 1 -maxdepth 1 ! -name final -exec rm -rf {} +
+du -sh gpurun_out | cut -f1
+ls $OUT
