@@ -239,6 +239,7 @@ int ses_env_reset(ses_handle *h, const float *init, int32_t n, void *state, floa
     SES_REQUIRE(h && init && state && obs, "ses_env_reset: null argument");
     SES_REQUIRE(n >= 1, "ses_env_reset: n must be >= 1");
     SES_REQUIRE(env_state_bytes(h) > 0, "ses_env_reset: handle has no env");
+    SES_REQUIRE(!h->cfg.physics64, "ses_env_reset: the step-wise CartPole is the float32 one (physics64 exists in the fused rollouts only)");
     SES_HIP_TRY(hipSetDevice(h->cfg.device));
     const dim3 grid(ceil_div(n, 64)), block(64);
     switch (h->cfg.env_id) {

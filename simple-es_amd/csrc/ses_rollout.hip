@@ -778,9 +778,13 @@ __global__ __launch_bounds__(64, EnvB::WAVES_PER_SIMD) void k_rollout_box2d_mlp(
         for (int k = 0; k < S; ++k) obs[k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
         if constexpr (LPE > 8) {
             // 16, 32 or 64 lanes per env: small populations, where an env that has a wave (or a good part of one) to itself
-            // pays for its own contacts, impacts and position iterations only, not for the union over its wave-mates';
-            // every lane evaluates the whole (tiny) policy, no cross-lane step
-            mlp_forward_streamed<S, A, 1>(theta + (size_t)row * P, 0, tanh_tab, obs, logits);
+            // pays for its own contacts, impacts and position iterations only, not for the union over its wave-mates'.
+            // The policy runs on each 16-lane row of the env's lanes (2 hidden units per lane, MlpSlice<.., 16>: ~90
+            // instructions and 30 weight loads per step; round 2 had every lane evaluate the whole policy from streamed
+            // weights: ~930 instructions and 420 dependent-ish loads, a tenth of a lander step)
+            MlpSlice<S, A, 16> net;
+            net.load(theta + (size_t)row * P, (int)(threadIdx.x & 15));
+            net.forward(tanh_tab, obs, logits);
         } else if constexpr (LPE >= 4) {
             MlpSlice<S, A, LPE> net;
             net.load(theta + (size_t)row * P, sub);

@@ -52,8 +52,9 @@ class GymWrapper:
         if self._dev is None:
             from ses import HipES
             sp = self.spec
+            # (env.physics: float64 exists in the fused rollouts only: the library refuses a step-wise reset of such a handle)
             self._dev = HipES(self.name, sp["num_state"], sp["num_action"], sp["discrete"], False, pomdp=self.pomdp,
-                              max_step=self.horizon, eval_ep_num=1)
+                              max_step=self.horizon, eval_ep_num=1, physics64=self.physics64)
         return self._dev
 
     def reset(self):

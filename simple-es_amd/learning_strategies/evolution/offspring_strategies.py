@@ -213,8 +213,15 @@ class _DeviceStrategy(BaseOffspringStrategy):
         if self.noise == "numpy":
             rows = self.dev.gather_rows(last["theta"], ids)
         else:
+            # the elite rows are not "the next population": this launch must not write the loop's tail time stamp
+            # (ses_set_stamp), or eval_t could be read before the population-writing launch has stamped it
+            keep = getattr(self.dev, "_stamp_keepalive", None)
+            if keep is not None:
+                self.dev.set_stamp(None)
             rows = self.dev.perturb(last["parents"], last["sigma"], self.seed, last["gen"], 0, k,
                                     parent_idx=sel, row_ids=ids, idx_in_range=True)   # map checked at upload
+            if keep is not None:
+                self.dev.set_stamp(keep)
         return rows, alias
 
     @property
