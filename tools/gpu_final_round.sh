@@ -9,6 +9,7 @@ TAG=${1:-r03}
 FUZZ=${2:-240}
 OUT=gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.txt 2>&1; echo "smoke rc=$?"; tail -1 $OUT/${TAG}_smoke.txt
 python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/${TAG}_pytest_gpu.log
 bash tools/gpu_profile_round.sh > $OUT/profile_round.txt 2>&1; tail -3 $OUT/profile_round.txt | cut -c1-200
 bash tools/prof_mfma.sh > gpurun_out/sq_mfma.txt 2>&1
