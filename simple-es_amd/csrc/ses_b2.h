@@ -403,13 +403,13 @@ B2_FN void collide(World<D> &w, const T &terr)
 // ------------------------------------------------------------------------------------------------------------------
 // b2RevoluteJoint
 template <class D>
-B2_FN void joint_init(World<D> &w, int j, JointTmp &t, float dt)
+B2_FN void joint_init(Body (&body)[D::NB], Joint (&joint)[D::NJ], const Xf (&xf)[D::NB], int j, JointTmp &t, float dt)
 {
     const JointDef &jd = D::joint()[j];
-    Joint &J = w.joint[j];
+    Joint &J = joint[j];
     const BodyDef &da = D::body()[jd.a], &db = D::body()[jd.b];
-    const Xf &qa = w.xf[jd.a], &qb = w.xf[jd.b];
-    Body &A = w.body[jd.a], &B = w.body[jd.b];
+    const Xf &qa = xf[jd.a], &qb = xf[jd.b];
+    Body &A = body[jd.a], &B = body[jd.b];
     {
         const float ax = jd.lax - da.lcx, ay = jd.lay - da.lcy, bx = jd.lbx - db.lcx, by = jd.lby - db.lcy;
         t.rax = qa.c * ax - qa.s * ay; t.ray = qa.s * ax + qa.c * ay;
@@ -469,12 +469,12 @@ B2_FN void joint_init(World<D> &w, int j, JointTmp &t, float dt)
 // SolveVelocityConstraints).  This is the innermost loop of the world (180 x NJ per step), so it is written with fused
 // multiply-adds and the pre-negated inverse mass matrix; Box2D's x86 build rounds every product separately.
 template <class D>
-B2_FN void joint_solve_velocity(World<D> &w, int j, const JointTmp &t)
+B2_FN void joint_solve_velocity(Body (&body)[D::NB], Joint (&joint)[D::NJ], int j, const JointTmp &t)
 {
     const JointDef &jd = D::joint()[j];
-    Joint &J = w.joint[j];
+    Joint &J = joint[j];
     const BodyDef &da = D::body()[jd.a], &db = D::body()[jd.b];
-    Body &A = w.body[jd.a], &B = w.body[jd.b];
+    Body &A = body[jd.a], &B = body[jd.b];
     const float mA = da.inv_mass, mB = db.inv_mass, iA = da.inv_i, iB = db.inv_i;
     const bool equal_limits = b2abs(jd.upper - jd.lower) < 2.0f * ANGULAR_SLOP;   // a constant of the joint
     if (!equal_limits) {                                      // motor (enableMotor = true)
@@ -511,12 +511,12 @@ B2_FN void joint_solve_velocity(World<D> &w, int j, const JointTmp &t)
 }
 
 template <class D>
-B2_FN bool joint_solve_position(World<D> &w, int j)
+B2_FN bool joint_solve_position(Body (&body)[D::NB], const Joint (&joint)[D::NJ], int j)
 {
     const JointDef &jd = D::joint()[j];
-    const Joint &J = w.joint[j];
+    const Joint &J = joint[j];
     const BodyDef &da = D::body()[jd.a], &db = D::body()[jd.b];
-    Body &A = w.body[jd.a], &B = w.body[jd.b];
+    Body &A = body[jd.a], &B = body[jd.b];
     const float mA = da.inv_mass, mB = db.inv_mass, iA = da.inv_i, iB = db.inv_i;
     float motor_mass = iA + iB;
     if (motor_mass > 0.0f) motor_mass = 1.0f / motor_mass;
@@ -747,10 +747,76 @@ namespace b2l {
 // b2Island::Solve after the velocities have been integrated: constraint setup, warm start, velocity iterations, position
 // integration, position iterations, sleep.  `mc`: the manifolds the contact rows run over, [body][row] in row order --
 // the world's own slots, or a packed copy of them (world_step below).
+// The touching manifolds of a body, packed to the front in slot order (world_step_discrete, D::PACK_MANIFOLDS)
 template <class D>
+B2_FN void pack_manifolds(const World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::NSLOT])
+{
+    constexpr int NBS = D::NB - D::FIRST_SOLVED;
+    B2_UNROLL
+    for (int b = 0; b < NBS; ++b) {
+        B2_UNROLL
+        for (int r = 0; r < D::NSLOT; ++r) mc[b][r] = Manifold{-1, 0, 0, 0.0f, 0.0f, 0.0f, 0.0f, {0.0f, 0.0f}, {0.0f, 0.0f}, {0u, 0u}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+        int n = 0;
+        B2_UNROLL
+        for (int s = 0; s < D::NSLOT; ++s) {
+            const bool touching = w.mf[b][s].count > 0;
+            B2_UNROLL
+            for (int r = 0; r <= s; ++r) {
+                if (touching && n == r) mc[b][r] = w.mf[b][s];
+            }
+            n += touching ? 1 : 0;
+        }
+    }
+}
+
+// The same packing again for what the position iterations read of a manifold (type, count, local normal / point, the
+// points), from the world where it lies in memory.  Between the velocity iterations' set-up and the position
+// iterations these ten values per row are not used; read a second time behind a compiler barrier they do not occupy
+// registers during the 180 velocity iterations (16 rows x 10 registers of the walker's 512).  Same values, same results.
+template <class D>
+B2_FN void repack_geometry(const World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::NSLOT])
+{
+    constexpr int NBS = D::NB - D::FIRST_SOLVED;
+    asm volatile("" ::: "memory");
+    B2_UNROLL
+    for (int b = 0; b < NBS; ++b) {
+        B2_UNROLL
+        for (int r = 0; r < D::NSLOT; ++r) {                  // (every field anew: nothing of the first copy stays alive)
+            Manifold &c = mc[b][r];
+            c.count = 0; c.type = 0; c.lnx = 0.0f; c.lny = 0.0f; c.lpx = 0.0f; c.lpy = 0.0f;
+            c.px[0] = 0.0f; c.px[1] = 0.0f; c.py[0] = 0.0f; c.py[1] = 0.0f;
+        }
+        int n = 0;
+        B2_UNROLL
+        for (int s = 0; s < D::NSLOT; ++s) {
+            const Manifold &m = w.mf[b][s];
+            const bool touching = m.count > 0;
+            B2_UNROLL
+            for (int r = 0; r <= s; ++r) {
+                if (touching && n == r) {
+                    Manifold &c = mc[b][r];
+                    c.count = m.count; c.type = m.type; c.lnx = m.lnx; c.lny = m.lny; c.lpx = m.lpx; c.lpy = m.lpy;
+                    c.px[0] = m.px[0]; c.px[1] = m.px[1]; c.py[0] = m.py[0]; c.py[1] = m.py[1];
+                }
+            }
+            n += touching ? 1 : 0;
+        }
+    }
+}
+
+template <class D, bool REPACK = false>
 B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::NSLOT], float dt)
 {
     constexpr int NBS = D::NB - D::FIRST_SOLVED;
+    // The solver runs on copies of the bodies and joints that are indexed by constants only: the world itself is indexed
+    // by lane-dependent values elsewhere (manifold slots, the body of a time-of-impact event), which keeps it in memory
+    // on the device -- and every velocity update of the 180 iterations would be a store to it.
+    Body body[D::NB];
+    Joint joint[D::NJ];
+    B2_UNROLL
+    for (int b = 0; b < D::NB; ++b) body[b] = w.body[b];
+    B2_UNROLL
+    for (int j = 0; j < D::NJ; ++j) joint[j] = w.joint[j];
     ContactTmp ct[NBS][D::NSLOT];
     JointTmp jt[D::NJ];
     bool any_contact = false;
@@ -758,29 +824,29 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
     for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
         B2_UNROLL
         for (int r = 0; r < D::NSLOT; ++r) {
-            contact_init(mc[b - D::FIRST_SOLVED][r], ct[b - D::FIRST_SOLVED][r], w.body[b], D::body()[b], w.xf[b]);
+            contact_init(mc[b - D::FIRST_SOLVED][r], ct[b - D::FIRST_SOLVED][r], body[b], D::body()[b], w.xf[b]);
             any_contact = any_contact || mc[b - D::FIRST_SOLVED][r].count > 0;
         }
     }
     B2_UNROLL
     for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
         B2_UNROLL
-        for (int r = 0; r < D::NSLOT; ++r) contact_warm_start(mc[b - D::FIRST_SOLVED][r], ct[b - D::FIRST_SOLVED][r], w.body[b], D::body()[b]);
+        for (int r = 0; r < D::NSLOT; ++r) contact_warm_start(mc[b - D::FIRST_SOLVED][r], ct[b - D::FIRST_SOLVED][r], body[b], D::body()[b]);
     }
     B2_UNROLL
-    for (int j = 0; j < D::NJ; ++j) joint_init(w, j, jt[j], dt);
+    for (int j = 0; j < D::NJ; ++j) joint_init<D>(body, joint, w.xf, j, jt[j], dt);
 
     // (no wave-level votes anywhere in this file: a world only ever looks at its own state, so the code may run
     //  under any divergence; in flight the contact rows are skipped as a whole)
     for (int it = 0; it < D::VEL_ITERS; ++it) {
         B2_UNROLL
-        for (int j = 0; j < D::NJ; ++j) joint_solve_velocity(w, j, jt[j]);
+        for (int j = 0; j < D::NJ; ++j) joint_solve_velocity<D>(body, joint, j, jt[j]);
         if (any_contact) {
             B2_UNROLL
             for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
                 B2_UNROLL
                 for (int r = 0; r < D::NSLOT; ++r)
-                    contact_solve_velocity(mc[b - D::FIRST_SOLVED][r], ct[b - D::FIRST_SOLVED][r], w.body[b], D::body()[b]);
+                    contact_solve_velocity(mc[b - D::FIRST_SOLVED][r], ct[b - D::FIRST_SOLVED][r], body[b], D::body()[b]);
             }
         }
     }
@@ -788,7 +854,7 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
     // integrate positions
     B2_UNROLL
     for (int b = 0; b < D::NB; ++b) {
-        Body &B = w.body[b];
+        Body &B = body[b];
         const float trx = dt * B.vx, try_ = dt * B.vy;
         if (trx * trx + try_ * try_ > MAX_TRANSLATION_SQ) {
             const float ratio = MAX_TRANSLATION / B2_SQRT(trx * trx + try_ * try_);
@@ -803,6 +869,8 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
         B.a += dt * B.w;
     }
 
+    if constexpr (REPACK) repack_geometry(w, mc);
+
     // position iterations with Box2D's own early exit
     bool position_solved = false;
     for (int pit = 0; pit < D::POS_ITERS && !position_solved; ++pit) {
@@ -813,14 +881,14 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
                 for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
                     B2_UNROLL
                     for (int r = 0; r < D::NSLOT; ++r)
-                        min_separation = b2min(min_separation, contact_solve_position(mc[b - D::FIRST_SOLVED][r], w.body[b], D::body()[b]));
+                        min_separation = b2min(min_separation, contact_solve_position(mc[b - D::FIRST_SOLVED][r], body[b], D::body()[b]));
                 }
             }
             const bool contacts_okay = min_separation >= -3.0f * LINEAR_SLOP;
             bool joints_okay = true;
             B2_UNROLL
             for (int j = 0; j < D::NJ; ++j) {
-                const bool ok = joint_solve_position(w, j);
+                const bool ok = joint_solve_position<D>(body, joint, j);
                 joints_okay = joints_okay && ok;
             }
             position_solved = contacts_okay && joints_okay;
@@ -831,7 +899,7 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
     float min_sleep = FLT_BIG;
     B2_UNROLL
     for (int b = 0; b < D::NB; ++b) {
-        const Body &B = w.body[b];
+        const Body &B = body[b];
         if (B.w * B.w > ANGULAR_SLEEP_TOL * ANGULAR_SLEEP_TOL || B.vx * B.vx + B.vy * B.vy > LINEAR_SLEEP_TOL * LINEAR_SLEEP_TOL) {
             w.sleep_time[b] = 0.0f;
             min_sleep = 0.0f;
@@ -841,6 +909,10 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
         }
     }
     if (min_sleep >= TIME_TO_SLEEP && position_solved) w.awake = false;
+    B2_UNROLL
+    for (int b = 0; b < D::NB; ++b) w.body[b] = body[b];
+    B2_UNROLL
+    for (int j = 0; j < D::NJ; ++j) w.joint[j] = joint[j];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1072,22 +1144,8 @@ B2_FN void world_step_discrete(World<D> &w, const T &terr, float dt, Sweep (&sw)
         // two edges: 2.5x on the rollout), not for the lander (2 x 2 slots).
         constexpr int NBS = D::NB - D::FIRST_SOLVED;
         Manifold mc[NBS][D::NSLOT];
-        B2_UNROLL
-        for (int b = 0; b < NBS; ++b) {
-            B2_UNROLL
-            for (int r = 0; r < D::NSLOT; ++r) mc[b][r] = Manifold{-1, 0, 0, 0.0f, 0.0f, 0.0f, 0.0f, {0.0f, 0.0f}, {0.0f, 0.0f}, {0u, 0u}, {0.0f, 0.0f}, {0.0f, 0.0f}};
-            int n = 0;
-            B2_UNROLL
-            for (int s = 0; s < D::NSLOT; ++s) {
-                const bool touching = w.mf[b][s].count > 0;
-                B2_UNROLL
-                for (int r = 0; r <= s; ++r) {
-                    if (touching && n == r) mc[b][r] = w.mf[b][s];
-                }
-                n += touching ? 1 : 0;
-            }
-        }
-        world_solve(w, mc, dt);
+        pack_manifolds(w, mc);
+        world_solve<D, true>(w, mc, dt);
         // the accumulated impulses go back to their slots (next step's warm start, b2Contact::Update in collide())
         B2_UNROLL
         for (int b = 0; b < NBS; ++b) {
