@@ -253,6 +253,7 @@ class WalkerSim:
     def debug(self):
         bodies = np.empty((5, 6), dtype=np.float32)
         terrain = np.empty(200, dtype=np.float32)
-        ints = np.zeros(6, dtype=np.int32)
+        ints = np.zeros(10, dtype=np.int32)
         lib().o_walker_debug(self._buf, _p(bodies), _p(terrain), _p(ints))
-        return bodies, terrain, {"game_over": int(ints[0]), "contact_points": int(ints[1]), "limits": ints[2:6].tolist()}
+        return bodies, terrain, {"game_over": int(ints[0]), "contact_points": int(ints[1]), "limits": ints[2:6].tolist(),
+                                 "manifolds_per_leg": ints[6:10].tolist()}

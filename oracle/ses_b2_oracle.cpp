@@ -161,7 +161,8 @@ float o_walker_step(void *state, const float *action4, float *obs, int32_t *done
     return r;
 }
 
-// diagnostics for the tests: bodies [5][6] (c, a, v, w), terrain [200], flags {game_over, contact points, limit states x4}
+// diagnostics for the tests: bodies [5][6] (c, a, v, w), terrain [200], flags {game_over, contact points, limit states x4,
+// touching manifolds of each leg body x4}
 void o_walker_debug(const void *state, float *bodies, float *terrain, int32_t *ints)
 {
     const WalkerSim *s = (const WalkerSim *)state;
@@ -177,6 +178,10 @@ void o_walker_debug(const void *state, float *bodies, float *terrain, int32_t *i
         for (int k = 0; k < 4; ++k) touching += s->env.w.mf[b][k].count;
     ints[1] = touching;
     for (int j = 0; j < 4; ++j) ints[2 + j] = s->env.w.joint[j].state;
+    for (int b = 0; b < 4; ++b) {
+        ints[6 + b] = 0;
+        for (int k = 0; k < 4; ++k) ints[6 + b] += s->env.w.mf[b][k].count > 0;
+    }
 }
 
 }  // extern "C"

@@ -94,11 +94,25 @@ struct Joint {                       // b2RevoluteJoint, the part that lives acr
 
 struct JointTmp {                    // InitVelocityConstraints results, alive for one step
     float rax, ray, rbx, rby;
-    float ezx, ezy;                  // m_mass.ez.x, .ez.y (the limit-release right-hand side)
     float n00, n01, n02, n11, n12, n22;   // MINUS the inverse of the symmetric 3x3 m_mass
-    float j00, j01, j11;             // inverse of its upper-left 2x2 block
     float motor_mass, max_impulse;   // max_impulse = dt * maxMotorTorque
 };
+
+struct JointRare {                   // the part of it that only a releasing limit reads (joint_solve_velocity): kept in
+    float ezx, ezy;                  // memory, not in registers, through the iterations -- m_mass.ez.x, .ez.y (the
+    float j00, j01, j11;             // limit-release right-hand side) and the inverse of m_mass's upper-left 2x2 block
+};
+
+// A pointer the compiler knows nothing about: what is stored through it stays in memory (device build: five registers
+// per joint less in the 180-iteration loop, which is what the last in-loop spills of the walker's solver were about).
+// development builds (-DSES_PHASE_TIMERS, tools/walker_phases.py) time the phases of a world step; nothing otherwise
+#ifndef B2_PHASE
+#define B2_PHASE(k)
+#endif
+
+#ifndef B2_OPAQUE_PTR
+#define B2_OPAQUE_PTR(p) asm volatile("" : "+r"(p)::"memory")
+#endif
 
 struct Manifold {                    // b2Manifold of (terrain edge `edge`, this body's polygon) + solver temporaries
     int edge;                        // -1: the slot is empty
@@ -403,7 +417,7 @@ B2_FN void collide(World<D> &w, const T &terr)
 // ------------------------------------------------------------------------------------------------------------------
 // b2RevoluteJoint
 template <class D>
-B2_FN void joint_init(Body (&body)[D::NB], Joint (&joint)[D::NJ], const Xf (&xf)[D::NB], int j, JointTmp &t, float dt)
+B2_FN void joint_init(Body (&body)[D::NB], Joint (&joint)[D::NJ], const Xf (&xf)[D::NB], int j, JointTmp &t, JointRare *rare, float dt)
 {
     const JointDef &jd = D::joint()[j];
     Joint &J = joint[j];
@@ -423,7 +437,8 @@ B2_FN void joint_init(Body (&body)[D::NB], Joint (&joint)[D::NJ], const Xf (&xf)
     const float eyy = mA + mB + t.rax * t.rax * iA + t.rbx * t.rbx * iB;
     const float ezy = t.rax * iA + t.rbx * iB;
     const float ezz = iA + iB;
-    t.ezx = ezx; t.ezy = ezy;
+    rare[j].ezx = ezx; rare[j].ezy = ezy;
+    float j00, j01, j11;
     {   // inverse by cofactors (b2Mat33::Solve33 divides by the same determinant)
         const float c00 = eyy * ezz - ezy * ezy, c01 = ezy * ezx - eyx * ezz, c02 = eyx * ezy - eyy * ezx;
         float det = exx * c00 + eyx * c01 + ezx * c02;
@@ -433,7 +448,8 @@ B2_FN void joint_init(Body (&body)[D::NB], Joint (&joint)[D::NJ], const Xf (&xf)
         t.n11 = -(det * c11); t.n12 = -(det * c12); t.n22 = -(det * c22);
         float d2 = exx * eyy - eyx * eyx;                    // b2Mat33::Solve22
         if (d2 != 0.0f) d2 = 1.0f / d2;
-        t.j00 = d2 * eyy; t.j01 = -d2 * eyx; t.j11 = d2 * exx;
+        j00 = d2 * eyy; j01 = -d2 * eyx; j11 = d2 * exx;
+        rare[j].j00 = j00; rare[j].j01 = j01; rare[j].j11 = j11;
     }
     t.motor_mass = iA + iB;
     if (t.motor_mass > 0.0f) t.motor_mass = 1.0f / t.motor_mass;
@@ -454,7 +470,7 @@ B2_FN void joint_init(Body (&body)[D::NB], Joint (&joint)[D::NJ], const Xf (&xf)
         }
     }
     if (J.state == LIMIT_INACTIVE) {      // no limit row this step: the point rows alone (2x2 block), written in the
-        t.n00 = -t.j00; t.n01 = -t.j01; t.n11 = -t.j11;        // same form so that the iteration below has one path
+        t.n00 = -j00; t.n01 = -j01; t.n11 = -j11;              // same form so that the iteration below has one path
         t.n02 = 0.0f; t.n12 = 0.0f; t.n22 = 0.0f;
     }
     // warm start (dtRatio = 1 for a constant time step: 50.0f * 0.02f rounds to 1.0f)
@@ -469,7 +485,7 @@ B2_FN void joint_init(Body (&body)[D::NB], Joint (&joint)[D::NJ], const Xf (&xf)
 // SolveVelocityConstraints).  This is the innermost loop of the world (180 x NJ per step), so it is written with fused
 // multiply-adds and the pre-negated inverse mass matrix; Box2D's x86 build rounds every product separately.
 template <class D>
-B2_FN void joint_solve_velocity(Body (&body)[D::NB], Joint (&joint)[D::NJ], int j, const JointTmp &t)
+B2_FN void joint_solve_velocity(Body (&body)[D::NB], Joint (&joint)[D::NJ], int j, const JointTmp &t, const JointRare *rare)
 {
     const JointDef &jd = D::joint()[j];
     Joint &J = joint[j];
@@ -497,9 +513,10 @@ B2_FN void joint_solve_velocity(Body (&body)[D::NB], Joint (&joint)[D::NJ], int 
         const bool release = J.state == LIMIT_LOWER ? new_impulse < 0.0f : new_impulse > 0.0f;
         if (release) {                                         // the limit lets go: solve the point rows alone
             B2_RARE_PATH;                                      // (rare: keep it a branch, not a select over both results)
-            const float rx = __builtin_fmaf(J.iz, t.ezx, -c1x), ry = __builtin_fmaf(J.iz, t.ezy, -c1y);
-            ix = __builtin_fmaf(t.j00, rx, t.j01 * ry);
-            iy = __builtin_fmaf(t.j01, rx, t.j11 * ry);
+            const JointRare q = rare[j];
+            const float rx = __builtin_fmaf(J.iz, q.ezx, -c1x), ry = __builtin_fmaf(J.iz, q.ezy, -c1y);
+            ix = __builtin_fmaf(q.j00, rx, q.j01 * ry);
+            iy = __builtin_fmaf(q.j01, rx, q.j11 * ry);
             iz = -J.iz;
         }
     }
@@ -819,6 +836,9 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
     for (int j = 0; j < D::NJ; ++j) joint[j] = w.joint[j];
     ContactTmp ct[NBS][D::NSLOT];
     JointTmp jt[D::NJ];
+    JointRare rare_mem[D::NJ];
+    JointRare *rare = rare_mem;
+    B2_OPAQUE_PTR(rare);
     bool any_contact = false;
     B2_UNROLL
     for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
@@ -834,13 +854,14 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
         for (int r = 0; r < D::NSLOT; ++r) contact_warm_start(mc[b - D::FIRST_SOLVED][r], ct[b - D::FIRST_SOLVED][r], body[b], D::body()[b]);
     }
     B2_UNROLL
-    for (int j = 0; j < D::NJ; ++j) joint_init<D>(body, joint, w.xf, j, jt[j], dt);
+    for (int j = 0; j < D::NJ; ++j) joint_init<D>(body, joint, w.xf, j, jt[j], rare, dt);
 
+    B2_PHASE(2);
     // (no wave-level votes anywhere in this file: a world only ever looks at its own state, so the code may run
     //  under any divergence; in flight the contact rows are skipped as a whole)
     for (int it = 0; it < D::VEL_ITERS; ++it) {
         B2_UNROLL
-        for (int j = 0; j < D::NJ; ++j) joint_solve_velocity<D>(body, joint, j, jt[j]);
+        for (int j = 0; j < D::NJ; ++j) joint_solve_velocity<D>(body, joint, j, jt[j], rare);
         if (any_contact) {
             B2_UNROLL
             for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
@@ -851,6 +872,7 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
         }
     }
 
+    B2_PHASE(3);
     // integrate positions
     B2_UNROLL
     for (int b = 0; b < D::NB; ++b) {
@@ -870,6 +892,7 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
     }
 
     if constexpr (REPACK) repack_geometry(w, mc);
+    B2_PHASE(4);
 
     // position iterations with Box2D's own early exit
     bool position_solved = false;
@@ -895,6 +918,7 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
         }
     }
 
+    B2_PHASE(5);
     // sleep (b2Island::Solve, the island = all bodies of the world)
     float min_sleep = FLT_BIG;
     B2_UNROLL
@@ -925,7 +949,6 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
 // restarts there ("leap of faith"), the contacts' velocity rows are solved from zero impulses for all velocity
 // iterations (joints are ignored in a sub-step, as in Box2D: their error is repaired by the next step), and the body
 // moves on for the rest of the step with the velocity it is left with.  Impulses of a sub-step are not kept.
-// Box2D caches a contact's TOI until one of its bodies moves; here every pair is re-evaluated after an event.
 constexpr float TOI_BAUMGARTE = 0.75f;
 constexpr int TOI_MAX_SUBSTEPS = 8;                  // b2_maxSubSteps, per contact and step
 
@@ -939,11 +962,21 @@ B2_FN void world_solve_toi(World<D> &w, const T &terr, Sweep (&sw)[D::NB], float
         B2_UNROLL
         for (int s = 0; s < D::NSLOT; ++s) { toi_count[b][s] = 0; disabled[b][s] = false; }
     }
+    // Box2D caches a contact's time of impact until one of its bodies moves (b2Contact::m_toi, e_toiFlag): so does this
+    // loop -- after an event only the body that took the sub-step has a new sweep, the others' pairs keep their alpha
+    float alpha_of[D::NB][D::NSLOT];
+    bool stale[D::NB];
+    B2_UNROLL
+    for (int b = 0; b < D::NB; ++b) stale[b] = true;
     for (int ev = 0; ev < D::NB * D::NSLOT * TOI_MAX_SUBSTEPS; ++ev) {
         float min_alpha = 1.0f;
         int min_b = -1, min_s = -1;
         B2_UNROLL
         for (int b = 0; b < D::NB; ++b) {
+          if (stale[b]) {
+            stale[b] = false;
+            B2_UNROLL
+            for (int s = 0; s < D::NSLOT; ++s) alpha_of[b][s] = 1.0f;
             const Poly &P = D::poly()[b];
             const BodyDef &bd = D::body()[b];
             // fattened AABB of the swept polygon (b2Fixture::Synchronize: the proxy covers both ends of the sweep);
@@ -1012,10 +1045,14 @@ B2_FN void world_solve_toi(World<D> &w, const T &terr, Sweep (&sw)[D::NB], float
                     if (!(ymin - AABB_EXTENSION > b2max(pr.ey[0], pr.ey[1])) && !out_of_reach) {
                         float t;
                         const int state = time_of_impact(pr, sw[b], bd, t);
-                        const float alpha = state == TOI_TOUCHING ? b2min(sw[b].alpha0 + (1.0f - sw[b].alpha0) * t, 1.0f) : 1.0f;
-                        if (alpha < min_alpha) { min_alpha = alpha; min_b = b; min_s = s; }
+                        alpha_of[b][s] = state == TOI_TOUCHING ? b2min(sw[b].alpha0 + (1.0f - sw[b].alpha0) * t, 1.0f) : 1.0f;
                     }
                 }
+            }
+          }
+            B2_UNROLL
+            for (int s = 0; s < D::NSLOT; ++s) {
+                if (alpha_of[b][s] < min_alpha) { min_alpha = alpha_of[b][s]; min_b = b; min_s = s; }
             }
         }
         if (min_b < 0 || 1.0f - 10.0f * 1.1920928955078125e-7f < min_alpha) break;
@@ -1023,6 +1060,7 @@ B2_FN void world_solve_toi(World<D> &w, const T &terr, Sweep (&sw)[D::NB], float
         B2_UNROLL
         for (int b = 0; b < D::NB; ++b) {
             if (b == min_b) {
+                stale[b] = true;
                 const BodyDef &bd = D::body()[b];
                 const Sweep backup = sw[b];
                 sweep_advance(sw[b], min_alpha);
@@ -1121,7 +1159,9 @@ B2_FN void world_step_discrete(World<D> &w, const T &terr, float dt, Sweep (&sw)
             sw[b].c0x = w.body[b].cx; sw[b].c0y = w.body[b].cy; sw[b].a0 = w.body[b].a; sw[b].alpha0 = 0.0f;
         }
     }
+    B2_PHASE(0);
     collide(w, terr);
+    B2_PHASE(1);
 
     // b2Island::Solve: integrate velocities (gravity, no damping: v *= 1 / (1 + h * 0) is exact)
     B2_UNROLL
@@ -1168,6 +1208,7 @@ B2_FN void world_step_discrete(World<D> &w, const T &terr, float dt, Sweep (&sw)
         B2_UNROLL
         for (int b = 0; b < D::NB; ++b) { sw[b].cx = w.body[b].cx; sw[b].cy = w.body[b].cy; sw[b].a = w.body[b].a; }
     }
+    B2_PHASE(6);
 }
 
 // The two halves of b2World::Step are separate functions because the device build keeps them in separate REAL
@@ -1178,9 +1219,11 @@ B2_FN void world_step_discrete(World<D> &w, const T &terr, float dt, Sweep (&sw)
 template <class D, class T>
 B2_FN void world_step_toi(World<D> &w, const T &terr, float dt, Sweep (&sw)[D::NB])
 {
+    B2_PHASE(7);
     if constexpr (D::CONTINUOUS) {
         if (w.awake) world_solve_toi(w, terr, sw, dt);
     }
+    B2_PHASE(8);
 }
 
 template <class D, class T>

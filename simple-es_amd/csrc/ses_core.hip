@@ -122,6 +122,7 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     h->tune_rollout_waves8 = 1024;
     h->tune_lander_per_wave = 0;
     h->tune_box2d_lpe = 0;
+    h->tune_box2d_epw = 0;
     h->tune_es_final_max_chunks = 0;          // measured: the wave-per-parameter update launch beats the in-kernel finisher
     *out = h;
     return SES_OK;
@@ -144,6 +145,7 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"rollout_mix_light", &ses_handle::tune_rollout_mix_light, 0, 16},
                                  {"lander_offspring_per_wave", &ses_handle::tune_lander_per_wave, 0, 4},
                                  {"box2d_lanes_per_env", &ses_handle::tune_box2d_lpe, 0, 64},
+                                 {"box2d_envs_per_wave", &ses_handle::tune_box2d_epw, 0, 64},
                                  {"es_final_max_chunks", &ses_handle::tune_es_final_max_chunks, 0, 1 << 20},
                                  {"comm_force_rccl", &ses_handle::tune_comm_force_rccl, 0, 1},
                                  {"comm_p2p_timeout_ms", &ses_handle::tune_comm_p2p_timeout_ms, 0, 1 << 30},

@@ -22,6 +22,36 @@
 #define B2_SQRT(x) __builtin_sqrtf(x)
 #define B2_FLOOR(x) __builtin_floorf(x)
 #define B2_RARE_PATH asm volatile("")
+#define B2_OPAQUE_PTR(p) asm volatile("" : "+v"(p)::"memory")
+#ifdef SES_PHASE_TIMERS
+// development build: cycles between consecutive marks of a wave by the phase that ended at the mark, accumulated in LDS
+// (single-wave workgroups) and added to the totals when the wave ends (phase_flush) -- no memory operation at a mark
+namespace ses {
+static __device__ unsigned long long phase_total[16];
+__device__ __forceinline__ unsigned long long *phase_lds()
+{
+    __shared__ unsigned long long a[17];
+    return a;
+}
+__device__ __forceinline__ void phase_mark(int k)
+{
+    unsigned long long *a = phase_lds();
+    const unsigned long long now = __builtin_readcyclecounter();
+    const unsigned long long m = __ballot(1);
+    if ((int)__lane_id() == __ffsll((long long)m) - 1) {
+        if (k >= 0) a[k] += now - a[16];
+        else for (int i = 0; i < 16; ++i) a[i] = 0;
+        a[16] = now;
+    }
+}
+__device__ __forceinline__ void phase_flush()
+{
+    unsigned long long *a = phase_lds();
+    if (__lane_id() < 16) atomicAdd(&phase_total[__lane_id()], a[__lane_id()]);
+}
+}  // namespace ses
+#define B2_PHASE(k) ses::phase_mark(k)
+#endif
 #define B2_F2U(f) ses::f2u(f)
 // two uniforms in (-1, 1) from the episode key and the step counter (oracle: ses_b2_oracle.cpp b2o_dispersion)
 #define B2_DISPERSION(k0, k1, step, d0, d1)                                                                     \

@@ -749,22 +749,28 @@ template <class EnvB, int LPE>
 __global__ __launch_bounds__(64, EnvB::WAVES_PER_SIMD) void k_rollout_box2d_mlp(const float *__restrict__ theta,
                                                            const float *__restrict__ init, int init_per_offspring,
                                                            int n_rows, int E, int P, int max_step, uint32_t obs_mask,
-                                                           double *__restrict__ ep_return,
+                                                           int envs_per_wave, double *__restrict__ ep_return,
                                                            int32_t *__restrict__ ep_steps)
 {
     constexpr int S = EnvB::S, A = EnvB::A;
     __shared__ TanhEntry tanh_tab[SES_TANH_N];
     __shared__ float terrain[64 / LPE][EnvB::ROW];                // one terrain row per env
     stage_tanh_table(tanh_tab);
-    const long long gtid = (long long)blockIdx.x * 64 + threadIdx.x;
+    // envs_per_wave <= 64 / LPE envs in this wave; the lane groups past the last one shadow it (same env, same path:
+    // they add nothing to what the wave executes) -- a wave-step costs about as much as it carries DIFFERENT envs
     const int n_env = n_rows * E;
-    int env = (int)(gtid / LPE);
+    const int group = (int)threadIdx.x / LPE;
+    const int slot = group < envs_per_wave ? group : envs_per_wave - 1;
+    int env = (int)blockIdx.x * envs_per_wave + slot;
     const int sub = (int)(threadIdx.x % LPE);
-    const bool valid = env < n_env;
-    env = valid ? env : n_env - 1;
+    const bool valid = env < n_env && group < envs_per_wave;
+    env = env < n_env ? env : n_env - 1;
     const int row = env / E, ep = env - row * E;
     typename EnvB::State st;
-    EnvB::reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * EnvB::INIT_W, terrain[threadIdx.x / LPE]);
+    EnvB::reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * EnvB::INIT_W, terrain[slot]);
+#ifdef SES_PHASE_TIMERS
+    phase_mark(-1);
+#endif
     double ret = 0.0;
     int steps = 0;
     bool done = false;
@@ -773,6 +779,9 @@ __global__ __launch_bounds__(64, EnvB::WAVES_PER_SIMD) void k_rollout_box2d_mlp(
         // the lane's weight slice is re-read from the (L2-resident) row every step: a few dozen loads next to a
         // 20 000-instruction world step, and nothing of the policy has to stay in registers across it
         float obs[S], logits[A], act[A];
+#ifdef SES_PHASE_TIMERS
+        phase_mark(10);
+#endif
         EnvB::observe(st, obs);
 #pragma unroll
         for (int k = 0; k < S; ++k) obs[k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
@@ -794,6 +803,11 @@ __global__ __launch_bounds__(64, EnvB::WAVES_PER_SIMD) void k_rollout_box2d_mlp(
         }
 #pragma unroll
         for (int k = 0; k < A; ++k) act[k] = tanh_(tanh_tab, logits[k]);
+#ifdef SES_PHASE_TIMERS
+#pragma unroll
+        for (int k = 0; k < A; ++k) asm volatile("" : "+v"(act[k]));   // the policy is done before the mark
+        phase_mark(11);
+#endif
         if (!done) {                                               // a finished env is frozen
             ret += (double)EnvB::step(st, act, done);
             steps += 1;
@@ -803,6 +817,9 @@ __global__ __launch_bounds__(64, EnvB::WAVES_PER_SIMD) void k_rollout_box2d_mlp(
         ep_return[env] = ret;
         if (ep_steps) ep_steps[env] = steps;
     }
+#ifdef SES_PHASE_TIMERS
+    phase_flush();
+#endif
 }
 
 // simple_spread: NA agents per env share the offspring's MLP (utils.py:4-8: one deepcopy per agent, same
@@ -1072,13 +1089,25 @@ static void launch_rollout(const ses_handle *h, const float *theta, const float 
 // eval_ep_num from which the GRU rollouts run on the matrix cores (ses_set_tuning "gru_mfma_min_e", default 12).
 // Measured, POMDP CartPole, 4096 offspring x 500 steps: the MFMA form takes 5.1 ms for any E <= 16 (the padded tile
 // costs the same), the VALU lockstep form 2.4 / 3.5 / 5.6 / 7.2 ms at E = 5 / 8 / 12 / 16 -- the crossover is at 12.
-// lanes per env of the Box2D MLP rollout: as many as keep the population within ~one wave per SIMD (1024 SIMDs)
-static int box2d_lanes_per_env(const ses_handle *h, long long episodes)
+// Envs per wave and lanes per env of the Box2D MLP rollout.  A wave-step costs about as much as the wave carries
+// different envs (the union of their contact rows, impacts, position iterations), so the population is spread over every
+// wave slot of the chip -- 1024 SIMDs x EnvB::WAVES_PER_SIMD, all resident at once -- with as few envs per wave as that
+// allows, and the lanes per env are the largest power of two that fits them.  BipedalWalker, 4096 x 5 episodes: 32 envs
+// on each of 640 waves 374 ms, 16 on each of 1280 (two rounds on 1024 slots) 356 ms, 20 on each of 1024 -> see DESIGN.md.
+// ses_set_tuning "box2d_lanes_per_env" forces LPE (and 64 / LPE envs per wave unless "box2d_envs_per_wave" is set too).
+static void box2d_wave_shape(const ses_handle *h, long long episodes, int waves_per_simd, int &lpe, int &epw)
 {
-    if (h->tune_box2d_lpe) return h->tune_box2d_lpe;
-    int lpe = 64;
-    while (lpe > 1 && episodes * lpe > 64ll * 1024) lpe >>= 1;
-    return lpe;
+    if (h->tune_box2d_lpe) {
+        lpe = h->tune_box2d_lpe;
+        epw = h->tune_box2d_epw ? h->tune_box2d_epw : 64 / lpe;
+        if (epw > 64 / lpe) epw = 64 / lpe;
+        return;
+    }
+    const long long slots = 1024ll * waves_per_simd;
+    long long need = h->tune_box2d_epw ? h->tune_box2d_epw : (episodes + slots - 1) / slots;
+    epw = (int)(need < 1 ? 1 : need > 64 ? 64 : need);
+    lpe = 64;
+    while (lpe > 1 && epw * lpe > 64) lpe >>= 1;
 }
 
 template <class EnvB>
@@ -1086,11 +1115,12 @@ static void launch_box2d_mlp(ses_handle *h, const float *theta, const float *ini
                              int32_t *ep_steps)
 {
     const long long episodes = (long long)n_rows * h->cfg.eval_ep_num;
-    const int lpe = box2d_lanes_per_env(h, episodes);
-    const dim3 grid(ceil_div(episodes * lpe, 64)), block(64);
+    int lpe, epw;
+    box2d_wave_shape(h, episodes, EnvB::WAVES_PER_SIMD, lpe, epw);
+    const dim3 grid(ceil_div(episodes, epw)), block(64);
 #define SES_BOX2D_LAUNCH(L)                                                                                          \
     hipLaunchKernelGGL((k_rollout_box2d_mlp<EnvB, L>), grid, block, 0, h->stream, theta, init, per, n_rows,           \
-                       h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, epr, ep_steps)
+                       h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, epw, epr, ep_steps)
     if (lpe == 64) SES_BOX2D_LAUNCH(64);
     else if (lpe == 32) SES_BOX2D_LAUNCH(32);
     else if (lpe == 16) SES_BOX2D_LAUNCH(16);
@@ -1446,3 +1476,16 @@ int ses_policy_forward(ses_handle *h, const float *theta, const float *obs, floa
 }
 
 }  // extern "C"
+
+#ifdef SES_PHASE_TIMERS
+// development build only (tools/walker_phases.py): the phase totals of ses_lander.h's phase_mark, read and optionally cleared
+extern "C" int ses_debug_phase_totals(unsigned long long *out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ses::phase_total), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ses::phase_total), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -49,7 +49,10 @@ __device__ __attribute__((noinline)) float bw_step_end(WalkerState &s, bool &don
 __device__ __attribute__((noinline)) float bw_step(WalkerState &s, float a0, float a1, float a2, float a3, bool &done)
 {
     {
+        B2_PHASE(12);
         b2l::WalkerEnv e = s.env;
+        asm volatile("" ::: "memory");
+        B2_PHASE(13);
         const b2l::WalkerTerrain terr{s.ty};
         const float act[4] = {a0, a1, a2, a3};
         b2l::WalkerPending pd;
