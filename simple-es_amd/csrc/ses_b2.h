@@ -1090,25 +1090,28 @@ B2_FN void world_solve_toi(World<D> &w, const T &terr, Sweep (&sw)[D::NB], float
                 } else if (b >= D::FIRST_SOLVED) {
                     // b2Island::SolveTOI on this body alone
                     const int bi = b >= D::FIRST_SOLVED ? b - D::FIRST_SOLVED : 0;
-                    Body &B = w.body[b];
+                    // the sub-step works on copies of the body and of its manifolds (constant indices: registers on the
+                    // device, not the world's memory -- its loops would store the body after every row)
+                    Body B = w.body[b];
+                    Manifold mt[D::NSLOT];
+                    B2_UNROLL
+                    for (int s = 0; s < D::NSLOT; ++s) {
+                        mt[s] = w.mf[bi][s];
+                        mt[s].ni[0] = 0.0f; mt[s].ni[1] = 0.0f; mt[s].ti[0] = 0.0f; mt[s].ti[1] = 0.0f;   // no warm starting
+                    }
                     for (int i = 0; i < 20; ++i) {
                         float min_separation = 0.0f;
                         B2_UNROLL
                         for (int s = 0; s < D::NSLOT; ++s)
-                            min_separation = b2min(min_separation, contact_solve_position(w.mf[bi][s], B, bd, TOI_BAUMGARTE));
+                            min_separation = b2min(min_separation, contact_solve_position(mt[s], B, bd, TOI_BAUMGARTE));
                         if (min_separation >= -1.5f * LINEAR_SLOP) break;
                     }
                     sw[b].c0x = B.cx; sw[b].c0y = B.cy; sw[b].a0 = B.a;     // leap of faith to the new safe state
                     Xf xf;
                     xf_of(B, bd, xf);
-                    Manifold mt[D::NSLOT];
                     ContactTmp ct[D::NSLOT];
                     B2_UNROLL
-                    for (int s = 0; s < D::NSLOT; ++s) {
-                        mt[s] = w.mf[bi][s];
-                        mt[s].ni[0] = 0.0f; mt[s].ni[1] = 0.0f; mt[s].ti[0] = 0.0f; mt[s].ti[1] = 0.0f;   // no warm starting
-                        contact_init(mt[s], ct[s], B, bd, xf);
-                    }
+                    for (int s = 0; s < D::NSLOT; ++s) contact_init(mt[s], ct[s], B, bd, xf);
                     // all D::VEL_ITERS iterations, as in Box2D (subStep.velocityIterations = step.velocityIterations) -- but
                     // an iteration that leaves the body's velocity and every accumulated impulse bit for bit where they
                     // were is a fixed point of the map, and so are all the iterations after it: stop there.  (One body
@@ -1143,6 +1146,7 @@ B2_FN void world_solve_toi(World<D> &w, const T &terr, Sweep (&sw)[D::NB], float
                     B.cx += h * B.vx; B.cy += h * B.vy;
                     B.a += h * B.w;
                     sw[b].cx = B.cx; sw[b].cy = B.cy; sw[b].a = B.a;
+                    w.body[b] = B;
                 }
             }
         }

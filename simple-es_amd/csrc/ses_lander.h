@@ -30,8 +30,8 @@ namespace ses {
 static __device__ unsigned long long phase_total[16];
 __device__ __forceinline__ unsigned long long *phase_lds()
 {
-    __shared__ unsigned long long a[17];
-    return a;
+    __shared__ unsigned long long a[4][17];                    // per wave of the workgroup (<= 4)
+    return a[(threadIdx.x >> 6) & 3];
 }
 __device__ __forceinline__ void phase_mark(int k)
 {

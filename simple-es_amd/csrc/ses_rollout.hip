@@ -498,11 +498,17 @@ __device__ __forceinline__ void gru_lockstep_multi_batch(const TanhEntry *tanh_t
         }
     }
     wave_lds_sync();
+#ifdef SES_PHASE_TIMERS
+    phase_mark(-1);
+#endif
     double ret = 0.0;
     int steps = 0;
     bool alive = true;
     for (int t = 0; t < max_step; ++t) {
         if (__ballot(alive & owner_valid) == 0ull) break;
+#ifdef SES_PHASE_TIMERS
+        phase_mark(10);
+#endif
         float obs[S];
         EnvT::observe(st, obs);
         float logits[A];
@@ -528,6 +534,11 @@ __device__ __forceinline__ void gru_lockstep_multi_batch(const TanhEntry *tanh_t
 #pragma unroll
             for (int o = 0; o < A; ++o) logits[o] = gl == g ? lg[o] : logits[o];
         }
+#ifdef SES_PHASE_TIMERS
+#pragma unroll
+        for (int o = 0; o < A; ++o) asm volatile("" : "+v"(logits[o]));
+        phase_mark(11);
+#endif
         bool term;
         const bool freeze = !(alive & owner_valid);
         const float r = EnvT::step(st, logits, tanh_tab, freeze, term);
@@ -541,6 +552,9 @@ __device__ __forceinline__ void gru_lockstep_multi_batch(const TanhEntry *tanh_t
         if (ep_return) ep_return[(size_t)my_row * E + slot] = ret;
         if (ep_steps) ep_steps[(size_t)my_row * E + slot] = steps;
     }
+#ifdef SES_PHASE_TIMERS
+    phase_flush();
+#endif
 }
 
 template <typename EnvT, int G>

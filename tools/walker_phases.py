@@ -2,7 +2,7 @@
 """Where a BipedalWalker (or LunarLander MLP) rollout spends its wave-cycles, by phase of the env step.  Needs a library
 built with -DSES_PHASE_TIMERS (SES_OUT=ab/libT.so csrc/build.sh -DSES_PHASE_TIMERS; SES_LIB_PATH=ab/libT.so): the marks
 of ses_b2.h (B2_PHASE) sum, over all waves, the cycles between consecutive marks.
-usage: walker_phases.py <lander|walker> [offspring] [lpe:epw]"""
+usage: walker_phases.py <lander|walker|c3> [offspring] [lpe:epw]      (c3: LunarLander POMDP GRU, the lockstep kernel)"""
 import ctypes, json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,13 +13,13 @@ from ses import _lib
 which = sys.argv[1] if len(sys.argv) > 1 else "walker"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 lpe, epw = (int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "0:0").split(":"))
-env, S = ("LunarLanderContinuous-v2", 8) if which == "lander" else ("BipedalWalker-v3", 24)
+env, S = ("BipedalWalker-v3", 24) if which == "walker" else ("LunarLanderContinuous-v2", 8)
 NAMES = ["call of the step, state copy in, motors", "collide", "integrate v, pack, contact / joint init, warm start",
          "velocity iterations", "integrate positions, re-pack", "position iterations", "sleep, write-back", "between the halves",
          "time of impact", "lidar rays (walker)", "reward, state copy out, return, loop", "observation + policy", "call of bw_step (walker)", "state copy in (walker)"]
-es = HipES(env, S, 4, False, False, max_step=300, eval_ep_num=5)
+es = HipES(env, S, 4, False, which == "c3", pomdp=which == "c3", max_step=300, eval_ep_num=5)
 es.set_tuning("box2d_lanes_per_env", lpe); es.set_tuning("box2d_envs_per_wave", epw)
-theta = es.perturb(es.zeros(es.P), 2.0, 0, 0, 0, n)
+theta = es.perturb(es.zeros(es.P), 0.5 if which == "c3" else 2.0, 0, 0, 0, n)
 init = es.init_states_uniform(0, 0, 0, n)
 fit = es.empty(n)
 lib = ctypes.CDLL(_lib.LIB_PATH)
