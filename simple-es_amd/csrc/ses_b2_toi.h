@@ -46,22 +46,48 @@ struct ToiPair {                     // the two b2DistanceProxy of a (terrain ed
     const Poly *P;                   // proxy B: local vertices P->vx[i], P->vy[i], i < P->n
 };
 
-B2_FN float edge_x(const ToiPair &p, int i) { return i ? p.ex[1] : p.ex[0]; }     // selects, not indexed private memory
-B2_FN float edge_y(const ToiPair &p, int i) { return i ? p.ey[1] : p.ey[0]; }
+// What time_of_impact works on: the pair by value, polygon included.  Vertices are picked by index with selects (vertex_x /
+// vertex_y) and every loop over them has a constant trip count, so on the device the whole pair sits in registers -- read
+// through the ToiPair it was a load from (constant or private) memory per vertex access inside the root finder's loops.
+struct ToiLocal {
+    float ex[2], ey[2];
+    float vx[6], vy[6];
+    int n;
+};
+
+B2_FN float edge_x(const ToiLocal &p, int i) { return i ? p.ex[1] : p.ex[0]; }    // selects, not indexed private memory
+B2_FN float edge_y(const ToiLocal &p, int i) { return i ? p.ey[1] : p.ey[0]; }
+B2_FN float vertex_x(const ToiLocal &p, int i)
+{
+    float r = p.vx[0];
+    B2_UNROLL
+    for (int k = 1; k < 6; ++k) r = i == k ? p.vx[k] : r;
+    return r;
+}
+B2_FN float vertex_y(const ToiLocal &p, int i)
+{
+    float r = p.vy[0];
+    B2_UNROLL
+    for (int k = 1; k < 6; ++k) r = i == k ? p.vy[k] : r;
+    return r;
+}
 
 // b2DistanceProxy::GetSupport
-B2_FN int support_edge(const ToiPair &p, float dx, float dy)
+B2_FN int support_edge(const ToiLocal &p, float dx, float dy)
 {
     const float v0 = p.ex[0] * dx + p.ey[0] * dy, v1 = p.ex[1] * dx + p.ey[1] * dy;
     return v1 > v0 ? 1 : 0;
 }
-B2_FN int support_poly(const ToiPair &p, float dx, float dy)
+B2_FN int support_poly(const ToiLocal &p, float dx, float dy)
 {
     int best = 0;
-    float best_value = p.P->vx[0] * dx + p.P->vy[0] * dy;
-    for (int i = 1; i < p.P->n; ++i) {
-        const float value = p.P->vx[i] * dx + p.P->vy[i] * dy;
-        if (value > best_value) { best = i; best_value = value; }
+    float best_value = p.vx[0] * dx + p.vy[0] * dy;
+    B2_UNROLL
+    for (int i = 1; i < 6; ++i) {
+        if (i < p.n) {
+            const float value = p.vx[i] * dx + p.vy[i] * dy;
+            if (value > best_value) { best = i; best_value = value; }
+        }
     }
     return best;
 }
@@ -77,11 +103,11 @@ struct SVertex {                     // b2SimplexVertex
     int ia, ib;
 };
 
-B2_FN void svertex_set(SVertex &v, const ToiPair &p, const Xf &xfB, int ia, int ib)
+B2_FN void svertex_set(SVertex &v, const ToiLocal &p, const Xf &xfB, int ia, int ib)
 {
     v.ia = ia; v.ib = ib;
     v.wax = edge_x(p, ia); v.way = edge_y(p, ia);                              // b2Mul(identity, vertexA)
-    const float lx = p.P->vx[ib], ly = p.P->vy[ib];
+    const float lx = vertex_x(p, ib), ly = vertex_y(p, ib);
     v.wbx = (xfB.c * lx - xfB.s * ly) + xfB.px; v.wby = (xfB.s * lx + xfB.c * ly) + xfB.py;
     v.wx = v.wbx - v.wax; v.wy = v.wby - v.way;
 }
@@ -100,7 +126,7 @@ B2_FN float simplex_metric(const SVertex (&v)[3], int count)
 }
 
 // b2Distance (useRadii = false): distance between the core shapes at transform xfB of the polygon; updates the cache
-B2_FN float gjk_distance(SimplexCache &cache, const ToiPair &p, const Xf &xfB)
+B2_FN float gjk_distance(SimplexCache &cache, const ToiLocal &p, const Xf &xfB)
 {
     constexpr float EPS = 1.1920928955078125e-7f;
     SVertex v[3];
@@ -223,14 +249,14 @@ struct SepFn {
     float ax, ay;                    // m_axis
 };
 
-B2_FN void sepfn_init(SepFn &f, const SimplexCache &cache, const ToiPair &p, const Sweep &sw, const BodyDef &bd, float t1)
+B2_FN void sepfn_init(SepFn &f, const SimplexCache &cache, const ToiLocal &p, const Sweep &sw, const BodyDef &bd, float t1)
 {
     Xf xfB;
     sweep_xf(sw, bd, t1, xfB);
     if (cache.count == 1) {
         f.type = 0;
         const float pax = edge_x(p, cache.ia[0]), pay = edge_y(p, cache.ia[0]);
-        const float lx = p.P->vx[cache.ib[0]], ly = p.P->vy[cache.ib[0]];
+        const float lx = vertex_x(p, cache.ib[0]), ly = vertex_y(p, cache.ib[0]);
         const float pbx = (xfB.c * lx - xfB.s * ly) + xfB.px, pby = (xfB.s * lx + xfB.c * ly) + xfB.py;
         f.ax = pbx - pax; f.ay = pby - pay;
         const float len = B2_SQRT(f.ax * f.ax + f.ay * f.ay);               // b2Vec2::Normalize
@@ -238,7 +264,7 @@ B2_FN void sepfn_init(SepFn &f, const SimplexCache &cache, const ToiPair &p, con
         f.lpx = 0.0f; f.lpy = 0.0f;
     } else if (cache.ia[0] == cache.ia[1]) {                                 // two points on B, one on A
         f.type = 2;
-        const float b1x = p.P->vx[cache.ib[0]], b1y = p.P->vy[cache.ib[0]], b2x = p.P->vx[cache.ib[1]], b2y = p.P->vy[cache.ib[1]];
+        const float b1x = vertex_x(p, cache.ib[0]), b1y = vertex_y(p, cache.ib[0]), b2x = vertex_x(p, cache.ib[1]), b2y = vertex_y(p, cache.ib[1]);
         f.ax = 1.0f * (b2y - b1y); f.ay = -1.0f * (b2x - b1x);              // b2Cross(b2 - b1, 1.0f)
         const float len = B2_SQRT(f.ax * f.ax + f.ay * f.ay);
         if (!(len < 1.1920928955078125e-7f)) { const float inv = 1.0f / len; f.ax *= inv; f.ay *= inv; }
@@ -255,7 +281,7 @@ B2_FN void sepfn_init(SepFn &f, const SimplexCache &cache, const ToiPair &p, con
         const float len = B2_SQRT(f.ax * f.ax + f.ay * f.ay);
         if (!(len < 1.1920928955078125e-7f)) { const float inv = 1.0f / len; f.ax *= inv; f.ay *= inv; }
         f.lpx = 0.5f * (a1x + a2x); f.lpy = 0.5f * (a1y + a2y);
-        const float lx = p.P->vx[cache.ib[0]], ly = p.P->vy[cache.ib[0]];
+        const float lx = vertex_x(p, cache.ib[0]), ly = vertex_y(p, cache.ib[0]);
         const float pbx = (xfB.c * lx - xfB.s * ly) + xfB.px, pby = (xfB.s * lx + xfB.c * ly) + xfB.py;
         const float s = (pbx - f.lpx) * f.ax + (pby - f.lpy) * f.ay;
         if (s < 0.0f) { f.ax = -f.ax; f.ay = -f.ay; }
@@ -263,7 +289,7 @@ B2_FN void sepfn_init(SepFn &f, const SimplexCache &cache, const ToiPair &p, con
 }
 
 // b2SeparationFunction::FindMinSeparation (find == true: the support indices are chosen and returned) and ::Evaluate
-B2_FN float sepfn_eval(const SepFn &f, const ToiPair &p, const Sweep &sw, const BodyDef &bd, float t, bool find, int &ia, int &ib)
+B2_FN float sepfn_eval(const SepFn &f, const ToiLocal &p, const Sweep &sw, const BodyDef &bd, float t, bool find, int &ia, int &ib)
 {
     Xf xfB;
     sweep_xf(sw, bd, t, xfB);
@@ -272,7 +298,7 @@ B2_FN float sepfn_eval(const SepFn &f, const ToiPair &p, const Sweep &sw, const 
             ia = support_edge(p, f.ax, f.ay);
             ib = support_poly(p, xfB.c * (-f.ax) + xfB.s * (-f.ay), -xfB.s * (-f.ax) + xfB.c * (-f.ay));
         }
-        const float lx = p.P->vx[ib], ly = p.P->vy[ib];
+        const float lx = vertex_x(p, ib), ly = vertex_y(p, ib);
         const float pbx = (xfB.c * lx - xfB.s * ly) + xfB.px, pby = (xfB.s * lx + xfB.c * ly) + xfB.py;
         return (pbx - edge_x(p, ia)) * f.ax + (pby - edge_y(p, ia)) * f.ay;
     }
@@ -281,7 +307,7 @@ B2_FN float sepfn_eval(const SepFn &f, const ToiPair &p, const Sweep &sw, const 
             ia = -1;
             ib = support_poly(p, xfB.c * (-f.ax) + xfB.s * (-f.ay), -xfB.s * (-f.ax) + xfB.c * (-f.ay));
         }
-        const float lx = p.P->vx[ib], ly = p.P->vy[ib];
+        const float lx = vertex_x(p, ib), ly = vertex_y(p, ib);
         const float pbx = (xfB.c * lx - xfB.s * ly) + xfB.px, pby = (xfB.s * lx + xfB.c * ly) + xfB.py;
         return (pbx - f.lpx) * f.ax + (pby - f.lpy) * f.ay;
     }
@@ -299,8 +325,17 @@ constexpr int TOI_FAILED = 0, TOI_OVERLAPPED = 1, TOI_TOUCHING = 2, TOI_SEPARATE
 // b2TimeOfImpact with tMax = 1: the fraction t of the sweep at which the core shapes are `target` apart
 // A REAL function (B2_NOINLINE): called once per (body, candidate edge) and step; inlined at every call site it would
 // multiply the world step's code
-B2_NOINLINE int time_of_impact(const ToiPair &p, const Sweep &sw, const BodyDef &bd, float &t_out)
+B2_NOINLINE int time_of_impact(const ToiPair &pair, const Sweep &sweep, const BodyDef &body_def, float &t_result)
 {
+    // everything the iterations read, by value (see ToiLocal); the result leaves through t_result once, at the end
+    ToiLocal p;
+    p.ex[0] = pair.ex[0]; p.ex[1] = pair.ex[1]; p.ey[0] = pair.ey[0]; p.ey[1] = pair.ey[1];
+    p.n = pair.P->n;
+    B2_UNROLL
+    for (int i = 0; i < 6; ++i) { p.vx[i] = pair.P->vx[i]; p.vy[i] = pair.P->vy[i]; }
+    const Sweep sw = sweep;
+    const BodyDef bd = body_def;
+    float t_out;
     const float total_radius = POLY_RADIUS + POLY_RADIUS;
     const float target = b2max(LINEAR_SLOP, total_radius - 3.0f * LINEAR_SLOP);
     const float tolerance = 0.25f * LINEAR_SLOP;
@@ -347,6 +382,7 @@ B2_NOINLINE int time_of_impact(const ToiPair &p, const Sweep &sw, const BodyDef 
         if (done) break;
         if (iter == 20) { state = TOI_FAILED; t_out = t1; break; }
     }
+    t_result = t_out;
     return state;
 }
 
