@@ -67,7 +67,10 @@ B2_FN float b2clamp(float a, float lo, float hi) { return b2max(lo, b2min(a, hi)
 B2_FN float b2abs(float a) { return a > 0.0f ? a : -a; }
 // clamp to [-lim, lim] in the solver's inner loops: fmin / fmax (one instruction each on the device; same value as
 // b2clamp for every non-NaN input)
-B2_FN float b2clamp_sym(float a, float lim) { return __builtin_fmaxf(-lim, __builtin_fminf(a, lim)); }
+#ifndef B2_CLAMP_SYM
+#define B2_CLAMP_SYM(a, lim) __builtin_fmaxf(-(lim), __builtin_fminf((a), (lim)))
+#endif
+B2_FN float b2clamp_sym(float a, float lim) { return B2_CLAMP_SYM(a, lim); }   // device: one v_med3_f32 (lim >= 0, no NaN: same value)
 
 struct JointDef {
     int a, b;                        // body indices
@@ -96,6 +99,7 @@ struct JointTmp {                    // InitVelocityConstraints results, alive f
     float rax, ray, rbx, rby;
     float n00, n01, n02, n11, n12, n22;   // MINUS the inverse of the symmetric 3x3 m_mass
     float motor_mass, max_impulse;   // max_impulse = dt * maxMotorTorque
+    float release_sign;              // +1 at the lower limit, -1 otherwise: the limit lets go when sign * impulse < 0
 };
 
 struct JointRare {                   // the part of it that only a releasing limit reads (joint_solve_velocity): kept in
@@ -469,6 +473,7 @@ B2_FN void joint_init(Body (&body)[D::NB], Joint (&joint)[D::NJ], const Xf (&xf)
             J.iz = 0.0f;
         }
     }
+    t.release_sign = J.state == LIMIT_LOWER ? 1.0f : -1.0f;
     if (J.state == LIMIT_INACTIVE) {      // no limit row this step: the point rows alone (2x2 block), written in the
         t.n00 = -j00; t.n01 = -j01; t.n11 = -j11;              // same form so that the iteration below has one path
         t.n02 = 0.0f; t.n12 = 0.0f; t.n22 = 0.0f;
@@ -510,7 +515,8 @@ B2_FN void joint_solve_velocity(Body (&body)[D::NB], Joint (&joint)[D::NJ], int 
     float iz = __builtin_fmaf(t.n02, c1x, __builtin_fmaf(t.n12, c1y, t.n22 * c2));
     if (!equal_limits) {
         const float new_impulse = J.iz + iz;                  // (inactive limit: J.iz = iz = 0, never released)
-        const bool release = J.state == LIMIT_LOWER ? new_impulse < 0.0f : new_impulse > 0.0f;
+        // lower limit: new_impulse < 0, upper: new_impulse > 0 -- one multiply by +-1 (exact) and one compare
+        const bool release = new_impulse * t.release_sign < 0.0f;
         if (release) {                                         // the limit lets go: solve the point rows alone
             B2_RARE_PATH;                                      // (rare: keep it a branch, not a select over both results)
             const JointRare q = rare[j];

@@ -22,6 +22,7 @@
 #define B2_SQRT(x) __builtin_sqrtf(x)
 #define B2_FLOOR(x) __builtin_floorf(x)
 #define B2_RARE_PATH asm volatile("")
+#define B2_CLAMP_SYM(a, lim) __builtin_amdgcn_fmed3f((a), -(lim), (lim))
 #define B2_OPAQUE_PTR(p) asm volatile("" : "+v"(p)::"memory")
 #ifdef SES_PHASE_TIMERS
 // development build: cycles between consecutive marks of a wave by the phase that ended at the mark, accumulated in LDS
