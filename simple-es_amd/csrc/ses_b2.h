@@ -871,9 +871,13 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
         if (any_contact) {
             B2_UNROLL
             for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
+                // packed rows: the first empty row of a body ends its rows (one test for a body in the air instead of NSLOT)
+                bool more = true;
                 B2_UNROLL
-                for (int r = 0; r < D::NSLOT; ++r)
-                    contact_solve_velocity(mc[b - D::FIRST_SOLVED][r], ct[b - D::FIRST_SOLVED][r], body[b], D::body()[b]);
+                for (int r = 0; r < D::NSLOT; ++r) {
+                    if (REPACK) more = more && ct[b - D::FIRST_SOLVED][r].vcount != 0;
+                    if (more) contact_solve_velocity(mc[b - D::FIRST_SOLVED][r], ct[b - D::FIRST_SOLVED][r], body[b], D::body()[b]);
+                }
             }
         }
     }
@@ -908,9 +912,13 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
             if (any_contact) {
                 B2_UNROLL
                 for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
+                    bool more = true;
                     B2_UNROLL
-                    for (int r = 0; r < D::NSLOT; ++r)
-                        min_separation = b2min(min_separation, contact_solve_position(mc[b - D::FIRST_SOLVED][r], body[b], D::body()[b]));
+                    for (int r = 0; r < D::NSLOT; ++r) {
+                        if (REPACK) more = more && mc[b - D::FIRST_SOLVED][r].count != 0;
+                        if (more)
+                            min_separation = b2min(min_separation, contact_solve_position(mc[b - D::FIRST_SOLVED][r], body[b], D::body()[b]));
+                    }
                 }
             }
             const bool contacts_okay = min_separation >= -3.0f * LINEAR_SLOP;
