@@ -41,6 +41,12 @@ done > $OUT/${TAG}_time_loop.txt
 python tools/time_loop.py lunarlander.yaml 0 300 2>&1 | tail -1 >> $OUT/${TAG}_time_loop.txt
 python tools/time_loop.py bipedalwalker.yaml 0 60 2>&1 | tail -1 >> $OUT/${TAG}_time_loop.txt
 cat $OUT/${TAG}_time_loop.txt
+python tools/time_box2d_mlp.py 4096 0 2>/dev/null > $OUT/${TAG}_box2d_mlp.txt; cat $OUT/${TAG}_box2d_mlp.txt | cut -c1-160
+python tools/walker_breakdown.py 4096 0 2>/dev/null > $OUT/${TAG}_walker_breakdown.txt
+# phase shares of an env step: a development build with timers (never the shipped library)
+mkdir -p ab
+SES_OUT=$R/ab/libT.so SES_OBJ=/tmp/objT bash simple-es_amd/csrc/build.sh -DSES_PHASE_TIMERS > /dev/null 2>&1
+for w in walker lander c3; do SES_LIB_PATH=$R/ab/libT.so python tools/walker_phases.py $w 4096 2>/dev/null; done > $OUT/${TAG}_step_phases.txt
 python tools/c3_breakdown.py > $OUT/${TAG}_c3_breakdown.txt 2>&1
 python tools/lander_step_cost.py > $OUT/${TAG}_lander_step_cost.txt 2>&1
 python tools/time_tail.py > $OUT/${TAG}_time_tail.txt 2>&1
