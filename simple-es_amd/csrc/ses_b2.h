@@ -1069,6 +1069,7 @@ B2_FN void world_solve_toi(World<D> &w, const T &terr, Sweep (&sw)[D::NB], float
                 if (alpha_of[b][s] < min_alpha) { min_alpha = alpha_of[b][s]; min_b = b; min_s = s; }
             }
         }
+        B2_PHASE(14);
         if (min_b < 0 || 1.0f - 10.0f * 1.1920928955078125e-7f < min_alpha) break;
         bool stop = false;
         B2_UNROLL
@@ -1164,6 +1165,7 @@ B2_FN void world_solve_toi(World<D> &w, const T &terr, Sweep (&sw)[D::NB], float
                 }
             }
         }
+        B2_PHASE(15);
         if (stop) break;
     }
 }

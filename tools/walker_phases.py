@@ -16,7 +16,8 @@ lpe, epw = (int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "0:0").split(
 env, S = ("BipedalWalker-v3", 24) if which == "walker" else ("LunarLanderContinuous-v2", 8)
 NAMES = ["call of the step, state copy in, motors", "collide", "integrate v, pack, contact / joint init, warm start",
          "velocity iterations", "integrate positions, re-pack", "position iterations", "sleep, write-back", "between the halves",
-         "time of impact", "lidar rays (walker)", "reward, state copy out, return, loop", "observation + policy", "call of bw_step (walker)", "state copy in (walker)"]
+         "time of impact: the rest", "lidar rays (walker)", "reward, state copy out, return, loop", "observation + policy", "call of bw_step (walker)", "state copy in (walker)", "time of impact: scans (reach tests, b2TimeOfImpact)",
+         "time of impact: events (contact update, sub-step solve)"]
 es = HipES(env, S, 4, False, which == "c3", pomdp=which == "c3", max_step=300, eval_ep_num=5)
 es.set_tuning("box2d_lanes_per_env", lpe); es.set_tuning("box2d_envs_per_wave", epw)
 theta = es.perturb(es.zeros(es.P), 0.5 if which == "c3" else 2.0, 0, 0, 0, n)
@@ -29,6 +30,6 @@ assert lib.ses_debug_phase_totals(buf, 1) == 0
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); es.rollout(theta, init, fitness=fit); e1.record(); e1.synchronize()
 assert lib.ses_debug_phase_totals(buf, 1) == 0
-tot = sum(buf[:14])
+tot = sum(buf[:16])
 print(json.dumps({"env": env, "offspring": n, "lanes_per_env": lpe, "envs_per_wave": epw, "rollout_ms_with_timers": round(e0.elapsed_time(e1), 2),
-                  "share": {NAMES[k]: round(buf[k] / tot, 4) for k in range(14)}}, indent=1))
+                  "share": {NAMES[k]: round(buf[k] / tot, 4) for k in range(16)}}, indent=1))
