@@ -729,11 +729,11 @@ __global__ __launch_bounds__(256, 2) void k_rollout_lander_gru(const float *__re
 }
 
 // MLP policies on the Box2D-style envs (LunarLander: conf/lunarlander.yaml, BipedalWalker: conf/bipedalwalker.yaml):
-// LPE lanes per env (LPE <= 8: 32 / LPE hidden units each for the forward; above: the whole forward in every lane), every
-// lane of a group carries the env.  The world
-// step is ~20 000 instructions whatever the number of lanes that carry an env, so LPE only decides how many waves the
-// population makes: box2d_lanes_per_env() picks the largest LPE (up to 64: one env per wave) that keeps it within one
-// wave per SIMD -- the fewer envs share a wave, the less each pays for the others' contacts and impacts.
+// LPE lanes per env (LPE <= 8: 32 / LPE hidden units each for the forward; above: the forward on every 16-lane row), every
+// lane of a group carries the env.  A wave-step costs a + b x (different envs in the wave) with a large a -- the solver's
+// sequential iterations, whatever the number of lanes that carry an env -- so box2d_wave_shape() spreads the population
+// over every wave slot of the chip with as few envs per wave as that allows (envs_per_wave), LPE follows from it, and
+// the lane groups past the last env shadow it (same env, same path).
 // Single-wave workgroups (they spread over all SIMDs and retire independently).  EnvB adapts an env.
 struct LanderMlpEnv {
     static constexpr int S = 8, A = 4, INIT_W = 16, ROW = LL_TERRAIN_ROW;
