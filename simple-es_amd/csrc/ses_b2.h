@@ -827,6 +827,28 @@ B2_FN void repack_geometry(const World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SO
     }
 }
 
+// one velocity iteration of the island: the joints in order, then the contact rows body by body
+template <class D, bool REPACK>
+B2_FN void velocity_iteration(Body (&body)[D::NB], Joint (&joint)[D::NJ], const JointTmp (&jt)[D::NJ], const JointRare *rare,
+                              Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::NSLOT],
+                              const ContactTmp (&ct)[D::NB - D::FIRST_SOLVED][D::NSLOT], bool any_contact)
+{
+    B2_UNROLL
+    for (int j = 0; j < D::NJ; ++j) joint_solve_velocity<D>(body, joint, j, jt[j], rare);
+    if (any_contact) {
+        B2_UNROLL
+        for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
+            // packed rows: the first empty row of a body ends its rows (one test for a body in the air instead of NSLOT)
+            bool more = true;
+            B2_UNROLL
+            for (int r = 0; r < D::NSLOT; ++r) {
+                if (REPACK) more = more && ct[b - D::FIRST_SOLVED][r].vcount != 0;
+                if (more) contact_solve_velocity(mc[b - D::FIRST_SOLVED][r], ct[b - D::FIRST_SOLVED][r], body[b], D::body()[b]);
+            }
+        }
+    }
+}
+
 template <class D, bool REPACK = false>
 B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::NSLOT], float dt)
 {
@@ -865,20 +887,67 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
     B2_PHASE(2);
     // (no wave-level votes anywhere in this file: a world only ever looks at its own state, so the code may run
     //  under any divergence; in flight the contact rows are skipped as a whole)
-    for (int it = 0; it < D::VEL_ITERS; ++it) {
-        B2_UNROLL
-        for (int j = 0; j < D::NJ; ++j) joint_solve_velocity<D>(body, joint, j, jt[j], rare);
-        if (any_contact) {
+    const auto iterate = [&]() __attribute__((always_inline)) {
+        velocity_iteration<D, REPACK>(body, joint, jt, rare, mc, ct, any_contact);
+    };
+    if constexpr (D::VEL_FIXED_POINT_CHECK < 0) {
+        for (int it = 0; it < D::VEL_ITERS; ++it) {
             B2_UNROLL
-            for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
-                // packed rows: the first empty row of a body ends its rows (one test for a body in the air instead of NSLOT)
-                bool more = true;
+            for (int j = 0; j < D::NJ; ++j) joint_solve_velocity<D>(body, joint, j, jt[j], rare);
+            if (any_contact) {
                 B2_UNROLL
-                for (int r = 0; r < D::NSLOT; ++r) {
-                    if (REPACK) more = more && ct[b - D::FIRST_SOLVED][r].vcount != 0;
-                    if (more) contact_solve_velocity(mc[b - D::FIRST_SOLVED][r], ct[b - D::FIRST_SOLVED][r], body[b], D::body()[b]);
+                for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
+                    bool more = true;
+                    B2_UNROLL
+                    for (int r = 0; r < D::NSLOT; ++r) {
+                        if (REPACK) more = more && ct[b - D::FIRST_SOLVED][r].vcount != 0;
+                        if (more) contact_solve_velocity(mc[b - D::FIRST_SOLVED][r], ct[b - D::FIRST_SOLVED][r], body[b], D::body()[b]);
+                    }
                 }
             }
+        }
+    } else {
+        // Three plain loops instead of one with a test inside: the iterations before the check, the checked one, the rest.
+        for (int it = 0; it < D::VEL_FIXED_POINT_CHECK; ++it) iterate();
+        // what the checked iteration starts from ...
+        Body body_was[D::NB];
+        Joint joint_was[D::NJ];
+        float imp_was[NBS][D::NSLOT][4];
+        B2_UNROLL
+        for (int b = 0; b < D::NB; ++b) body_was[b] = body[b];
+        B2_UNROLL
+        for (int j = 0; j < D::NJ; ++j) joint_was[j] = joint[j];
+        B2_UNROLL
+        for (int b = 0; b < NBS; ++b) {
+            B2_UNROLL
+            for (int r = 0; r < D::NSLOT; ++r) {
+                imp_was[b][r][0] = mc[b][r].ni[0]; imp_was[b][r][1] = mc[b][r].ni[1];
+                imp_was[b][r][2] = mc[b][r].ti[0]; imp_was[b][r][3] = mc[b][r].ti[1];
+            }
+        }
+        iterate();
+        // ... and what it ends with: the same bits (-0 is not +0 here) = a fixed point of the map = the result of all
+        // D::VEL_ITERS iterations.  (A lane that skips the rest waits for its wave-mates; no votes.)
+        uint32_t diff = 0u;
+        B2_UNROLL
+        for (int b = 0; b < D::NB; ++b)
+            diff |= (B2_F2U(body_was[b].vx) ^ B2_F2U(body[b].vx)) | (B2_F2U(body_was[b].vy) ^ B2_F2U(body[b].vy)) |
+                    (B2_F2U(body_was[b].w) ^ B2_F2U(body[b].w));
+        B2_UNROLL
+        for (int j = 0; j < D::NJ; ++j)
+            diff |= (B2_F2U(joint_was[j].ix) ^ B2_F2U(joint[j].ix)) | (B2_F2U(joint_was[j].iy) ^ B2_F2U(joint[j].iy)) |
+                    (B2_F2U(joint_was[j].iz) ^ B2_F2U(joint[j].iz)) | (B2_F2U(joint_was[j].im) ^ B2_F2U(joint[j].im));
+        if (any_contact) {
+            B2_UNROLL
+            for (int b = 0; b < NBS; ++b) {
+                B2_UNROLL
+                for (int r = 0; r < D::NSLOT; ++r)
+                    diff |= (B2_F2U(imp_was[b][r][0]) ^ B2_F2U(mc[b][r].ni[0])) | (B2_F2U(imp_was[b][r][1]) ^ B2_F2U(mc[b][r].ni[1])) |
+                            (B2_F2U(imp_was[b][r][2]) ^ B2_F2U(mc[b][r].ti[0])) | (B2_F2U(imp_was[b][r][3]) ^ B2_F2U(mc[b][r].ti[1]));
+            }
+        }
+        if (diff != 0u) {
+            for (int it = D::VEL_FIXED_POINT_CHECK + 1; it < D::VEL_ITERS; ++it) iterate();
         }
     }
 

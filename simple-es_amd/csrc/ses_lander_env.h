@@ -40,6 +40,11 @@ struct LanderDef {
     static constexpr int NB = 3, NJ = 2, NSLOT = 2, FIRST_SOLVED = 1, VEL_ITERS = 6 * 30, POS_ITERS = 2 * 30;
     static constexpr bool PACK_MANIFOLDS = false;    // 2 x 2 slots: the solver runs over them as they are
     static constexpr bool CONTINUOUS = true;         // b2World::SolveTOI against the terrain (ses_b2.h)
+    // The velocity iteration is a deterministic map of (velocities, accumulated impulses): once an iteration returns them
+    // bit for bit, every later one does.  Measured on the CPU build (first-generation C3 policies, 48 778 steps in flight):
+    // 58 % of the steps are at such a fixed point after <= 6 of the 180 iterations (limits inactive, motors saturated),
+    // 39 % never reach one; with contacts 3 % by iteration 20.  One comparison, after the iteration with this index.
+    static constexpr int VEL_FIXED_POINT_CHECK = 7;
     static constexpr float GRAVITY_Y = -10.0f;
     B2_FN const Poly *poly() { return LANDER_POLY; }
     B2_FN const BodyDef *body() { return LANDER_BODY; }
