@@ -150,6 +150,67 @@ __global__ __launch_bounds__(BLOCK) void k_copy13(int n4, int, f4v *x, f4v *xd, 
     }
 }
 
+// Out of place: the six arrays that are written go to a second set (ping-pong), nothing is written where it was read.
+template <bool ARITH, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_step_oop(int n4, int max_step, const f4v *x, const f4v *xd, const f4v *th, const f4v *thd,
+                                                    const i4v *action, const f4v *ret, const u4v *status, f4v *ox, f4v *oxd,
+                                                    f4v *oth, f4v *othd, f4v *oret, u4v *ostatus)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n4) return;
+    f4v vx = ld<true>(x + i), vxd = ld<true>(xd + i), vth = ld<true>(th + i), vthd = ld<true>(thd + i), vr = ld<true>(ret + i);
+    i4v va = ld<true>(action + i);
+    u4v vs = ld<true>(status + i);
+    if constexpr (ARITH) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            float ex = vx[l], exd = vxd[l], eth = vth[l], ethd = vthd[l], er = vr[l];
+            uint32_t es = vs[l];
+            step_one(ex, exd, eth, ethd, va[l], er, es, max_step);
+            vx[l] = ex; vxd[l] = exd; vth[l] = eth; vthd[l] = ethd; vr[l] = er; vs[l] = es;
+        }
+    } else {
+        asm volatile("" : "+v"(vx), "+v"(vxd), "+v"(vth), "+v"(vthd), "+v"(vr), "+v"(vs));
+        asm volatile("" ::"v"(va));
+    }
+    st<true>(ox + i, vx); st<true>(oxd + i, vxd); st<true>(oth + i, vth); st<true>(othd + i, vthd); st<true>(oret + i, vr);
+    st<true>(ostatus + i, vs);
+}
+
+// Tiled SoA: the seven arrays of G * BLOCK * 4 envs lie behind one another in one contiguous tile (7 x G x BLOCK float4
+// groups); a workgroup owns a tile.  Same 52 bytes per env-step, but a launch is one sequential read stream and one
+// sequential write stream over the allocation instead of seven + six concurrent ones.  ARITH = false: the copy ceiling.
+template <bool ARITH, int G, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_step_tiled(int n_tiles, int max_step, f4v *tiles)
+{
+    constexpr int SEG = G * BLOCK;                                          // float4 groups per array per tile
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        f4v *base = tiles + (size_t)t * 7 * SEG;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int i = g * BLOCK + threadIdx.x;
+            f4v vx = ld<true>(base + i), vxd = ld<true>(base + SEG + i), vth = ld<true>(base + 2 * SEG + i),
+                vthd = ld<true>(base + 3 * SEG + i), vr = ld<true>(base + 5 * SEG + i);
+            i4v va = ld<true>((const i4v *)(base + 4 * SEG) + i);
+            u4v vs = ld<true>((const u4v *)(base + 6 * SEG) + i);
+            if constexpr (ARITH) {
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    float ex = vx[l], exd = vxd[l], eth = vth[l], ethd = vthd[l], er = vr[l];
+                    uint32_t es = vs[l];
+                    step_one(ex, exd, eth, ethd, va[l], er, es, max_step);
+                    vx[l] = ex; vxd[l] = exd; vth[l] = eth; vthd[l] = ethd; vr[l] = er; vs[l] = es;
+                }
+            } else {
+                asm volatile("" : "+v"(vx), "+v"(vxd), "+v"(vth), "+v"(vthd), "+v"(vr), "+v"(vs));
+                asm volatile("" ::"v"(va));
+            }
+            st<true>(base + i, vx); st<true>(base + SEG + i, vxd); st<true>(base + 2 * SEG + i, vth);
+            st<true>(base + 3 * SEG + i, vthd); st<true>(base + 5 * SEG + i, vr); st<true>((u4v *)(base + 6 * SEG) + i, vs);
+        }
+    }
+}
+
 template <bool NT, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_copy2(long n4, const f4v *src, f4v *dst)
 {
@@ -213,6 +274,28 @@ int main(int argc, char **argv)
     ADD("CEILING copy13 nt one-shot b256", n4 / 256, 256, (k_copy13<true, 1, 256>));
     ADD("CEILING copy13 nt 2 x 16 B one-shot", n4 / 512, 256, (k_copy13<true, 2, 256>));
     ADD("CEILING copy13 nt persistent 2048 wg", 2048, 256, (k_copy13<true, 1, 256>));
+    // out of place: a second pool for the six written arrays
+    char *pool2;
+    CK(hipMalloc(&pool2, stride * 7));
+    CK(hipMemset(pool2, 0, stride * 7));
+    f4v *ox = (f4v *)(pool2 + 0 * stride), *oxd = (f4v *)(pool2 + 1 * stride), *oth = (f4v *)(pool2 + 2 * stride),
+        *othd = (f4v *)(pool2 + 3 * stride), *ort = (f4v *)(pool2 + 5 * stride);
+    u4v *ostt = (u4v *)(pool2 + 6 * stride);
+    vs.push_back({"OUT OF PLACE product (second set of arrays)", [=] { hipLaunchKernelGGL((k_step_oop<true, 256>), dim3(n4 / 256), dim3(256), 0, 0, n4, 0, x, xd, th, thd, ac, rt, stt, ox, oxd, oth, othd, ort, ostt); }, bytes, {}});
+    vs.push_back({"CEILING out-of-place copy13", [=] { hipLaunchKernelGGL((k_step_oop<false, 256>), dim3(n4 / 256), dim3(256), 0, 0, n4, 0, x, xd, th, thd, ac, rt, stt, ox, oxd, oth, othd, ort, ostt); }, bytes, {}});
+    // tiled layout: one allocation of n / tile_envs tiles
+    f4v *tiles;
+    CK(hipMalloc(&tiles, (size_t)n * 28));
+    CK(hipMemset(tiles, 0, (size_t)n * 28));
+#define ADDT(NAME, ARITH, G, BLOCK, GRID)                                                                                 \
+    vs.push_back({NAME, [=] { hipLaunchKernelGGL((k_step_tiled<ARITH, G, BLOCK>), dim3(GRID), dim3(BLOCK), 0, 0, n4 / (G * BLOCK), 0, tiles); }, bytes, {}})
+    ADDT("TILED 1024 envs/tile, b256, one-shot", true, 1, 256, n4 / 256);
+    ADDT("TILED 256 envs/tile, b64, one-shot", true, 1, 64, n4 / 64);
+    ADDT("TILED 4096 envs/tile, b256 x 4, one-shot", true, 4, 256, n4 / 1024);
+    ADDT("TILED 4096 envs/tile, b1024, one-shot", true, 1, 1024, n4 / 1024);
+    ADDT("TILED 1024 envs/tile, persistent 2048 wg", true, 1, 256, 2048);
+    ADDT("CEILING tiled copy 1024 envs/tile", false, 1, 256, n4 / 256);
+    ADDT("CEILING tiled copy 4096 envs/tile b256 x 4", false, 4, 256, n4 / 1024);
     vs.push_back({"CEILING copy2 nt (26 B in, 26 B out per env)", [=] { hipLaunchKernelGGL((k_copy2<true, 256>), dim3((unsigned)(c4 / 256)), dim3(256), 0, 0, c4, (const f4v *)c_src, c_dst); }, bytes, {}});
     vs.push_back({"CEILING copy2 plain", [=] { hipLaunchKernelGGL((k_copy2<false, 256>), dim3((unsigned)(c4 / 256)), dim3(256), 0, 0, c4, (const f4v *)c_src, c_dst); }, bytes, {}});
     vs.push_back({"CEILING hipMemcpyDtoD same bytes", [=] { (void)hipMemcpyAsync(c_dst, c_src, (size_t)(bytes / 2), hipMemcpyDeviceToDevice, 0); }, bytes, {}});
