@@ -162,6 +162,18 @@ def env_step_roofline(es, n_env, launches=20, batches=15, preroll=200):
     probe_avg = statistics.median(probes)
     achieved = BYTES_PER_ENV_STEP * n_env / avg / 1e9
     copy13 = BYTES_PER_ENV_STEP * n_env / probe_avg / 1e9
+    # the same kernel and probe with as many waves in flight as the CUs take (256 threads, no LDS reserved: the shape of
+    # rounds 1-3a): what limiting the waves in flight is worth on this box
+    es.set_tuning("env_step_block", 256)
+    es.set_tuning("env_step_lds_bytes", 0)
+    for _ in range(20):
+        step()
+    wide_steps, wide_probes = [], []
+    for _ in range(5):
+        wide_steps.append(batch(step, launches))
+        wide_probes.append(batch(probe, launches))
+    es.set_tuning("env_step_block", 64)
+    es.set_tuning("env_step_lds_bytes", 22528)
     # torch's device-to-device copy of the same byte count (read half, write half: two streams)
     half = BYTES_PER_ENV_STEP * n_env // 2
     src, dst = torch.empty(half, dtype=torch.uint8, device="cuda"), torch.empty(half, dtype=torch.uint8, device="cuda")
@@ -176,7 +188,12 @@ def env_step_roofline(es, n_env, launches=20, batches=15, preroll=200):
             "first_batch_us": first * 1e6, "first_batch_frac": BYTES_PER_ENV_STEP * n_env / first / 1e9 / HBM_PEAK_GBS,
             "best_batch_us": min(steps) * 1e6,
             "copy13_us": probe_avg * 1e6, "copy13_gbs": copy13, "frac_of_copy13": achieved / copy13,
-            "copy13": "ses_stream_probe: the same 7 load + 6 store streams, float4 non-temporal, no arithmetic, same grid",
+            "copy13": "ses_stream_probe: the same 7 load + 6 store streams, float4 non-temporal, no arithmetic, same launch shape",
+            "launch_shape": "single-wave workgroups, each reserving 22 KB of LDS it never touches: 7 waves per CU in flight "
+                            "(ses_env_step; tools/envstep_ab.hip has the sweep)",
+            "unlimited_waves_us": statistics.median(wide_steps) * 1e6,
+            "unlimited_waves_frac": BYTES_PER_ENV_STEP * n_env / statistics.median(wide_steps) / 1e9 / HBM_PEAK_GBS,
+            "unlimited_waves_copy13_us": statistics.median(wide_probes) * 1e6,
             "copy_same_bytes_gbs": copy_gbs, "frac_of_copy": achieved / copy_gbs,
             "env_steps_per_s": n_env / avg,
             "bytes_per_env_step": BYTES_PER_ENV_STEP}

@@ -92,6 +92,8 @@ int ses_sync(ses_handle *h);
  * "rollout_waves8" (1024: light waves of the mixed CartPole MLP split), "rollout_mix_light" (their lanes per env: 0 = choose | 8 | 16), "rollout_block" (64 | 256), "lander_offspring_per_wave" (0 = by population size | 1 | 2 | 4),
  * "box2d_lanes_per_env" (0 = by population size | 1 | 2 | ... | 64: lanes that share one env in the LunarLander / BipedalWalker MLP rollout),
  * "box2d_envs_per_wave" (0 = by population size | 1 ... 64 / lanes per env: different envs a wave of that rollout carries),
+ * "env_step_block" (64 | 128 | 256) and "env_step_lds_bytes" (0 ... 65536): workgroup size of ses_env_step's kernel and the LDS
+ * each workgroup reserves without touching it -- 64 and 22528 keep 7 waves per CU in flight, which is what the memory system wants,
  * "es_final_max_chunks" (0: ses_openai_generation applies Adam in its own small launch; k > 0: inside the gradient kernel for
  * populations of up to k * 1024 rows), "comm_force_rccl" (1: ses_allgather_fitness uses the RCCL communicator although the
  * peer-store transport is attached -- for measuring one against the other), "comm_p2p_timeout_ms" (how long a peer-store

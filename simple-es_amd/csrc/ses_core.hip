@@ -123,6 +123,8 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     h->tune_lander_per_wave = 0;
     h->tune_box2d_lpe = 0;
     h->tune_box2d_epw = 0;
+    h->tune_env_step_block = 64;
+    h->tune_env_step_lds = 22528;
     h->tune_es_final_max_chunks = 0;          // measured: the wave-per-parameter update launch beats the in-kernel finisher
     *out = h;
     return SES_OK;
@@ -146,6 +148,8 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"lander_offspring_per_wave", &ses_handle::tune_lander_per_wave, 0, 4},
                                  {"box2d_lanes_per_env", &ses_handle::tune_box2d_lpe, 0, 64},
                                  {"box2d_envs_per_wave", &ses_handle::tune_box2d_epw, 0, 64},
+                                 {"env_step_block", &ses_handle::tune_env_step_block, 64, 256},
+                                 {"env_step_lds_bytes", &ses_handle::tune_env_step_lds, 0, 65536},
                                  {"es_final_max_chunks", &ses_handle::tune_es_final_max_chunks, 0, 1 << 20},
                                  {"comm_force_rccl", &ses_handle::tune_comm_force_rccl, 0, 1},
                                  {"comm_p2p_timeout_ms", &ses_handle::tune_comm_p2p_timeout_ms, 0, 1 << 30},
@@ -155,6 +159,8 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
             SES_REQUIRE(value >= k.lo && value <= k.hi, "ses_set_tuning: %s = %d outside [%d, %d]", name, value, k.lo, k.hi);
             SES_REQUIRE(k.field != &ses_handle::tune_rollout_block || value == 64 || value == 256,
                         "ses_set_tuning: rollout_block must be 64 or 256");
+            SES_REQUIRE(k.field != &ses_handle::tune_env_step_block || value == 64 || value == 128 || value == 256,
+                        "ses_set_tuning: env_step_block must be 64, 128 or 256");
             SES_REQUIRE(k.field != &ses_handle::tune_lander_per_wave || value != 3,
                         "ses_set_tuning: lander_offspring_per_wave must be 0, 1, 2 or 4");
             SES_REQUIRE(k.field != &ses_handle::tune_box2d_lpe || (value & (value - 1)) == 0,

@@ -42,6 +42,8 @@ struct ses_handle {
     int tune_comm_force_rccl;      // 1: ses_allgather_fitness ignores an attached peer-store transport (A/B measurements)
     int tune_es_final_max_chunks;  // ses_openai_generation: up to this many 1024-row chunks the gradient kernel applies Adam itself
     int tune_box2d_lpe;            // lanes per env of the Box2D MLP rollout: 0 = by population size, 1 / 2 / 4 / ... / 64
+    int tune_env_step_block;       // threads per workgroup of the standalone env-step kernel (64)
+    int tune_env_step_lds;         // bytes of LDS each of its workgroups reserves without touching them: limits the waves in flight (22528)
     int tune_box2d_epw;            // different envs per wave of the Box2D MLP rollout: 0 = by population size, else <= 64 / lanes per env
     int tune_lander_per_wave;      // offspring per wave of the lockstep lander rollout: 0 = by population size, 1 / 2 / 4
     int tune_comm_p2p_timeout_ms;  // how long a peer-store exchange waits for a peer (0 = the default, 60 s)

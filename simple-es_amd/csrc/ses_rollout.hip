@@ -1250,6 +1250,20 @@ static void launch_cartpole_mlp(const ses_handle *h, const float *theta, const f
     }
 }
 
+// launch shape of the standalone env-step kernel (and of the probe that has to match it): see ses_env_step
+struct EnvStepShape {
+    int blocks, block, lds;
+};
+static EnvStepShape env_step_shape(const ses_handle *h, int n4)
+{
+    EnvStepShape sh;
+    sh.block = h->tune_env_step_block;
+    sh.lds = h->tune_env_step_lds;
+    const long long want = ceil_div((long long)n4, sh.block);
+    sh.blocks = want < (1 << 20) ? (int)want : (1 << 20);                   // beyond that the kernel strides
+    return sh;
+}
+
 }  // namespace ses
 
 extern "C" {
@@ -1407,14 +1421,19 @@ int ses_env_step(ses_handle *h, int32_t n, int32_t mode, float *x, float *xd, fl
     const int n4 = (align & 15u) ? 0 : n / 4;  // unaligned arrays take the scalar path entirely
     const int max_step = h->cfg.max_step;
     if (n4 > 0) {
-        // one float4 group per thread; a one-shot grid beat every grid-stride shape on MI355X (2^24 and 2^26 envs)
-        const int blocks = ceil_div(n4, 256) < (1 << 20) ? ceil_div(n4, 256) : (1 << 20);
+        // One float4 group per thread, a one-shot grid -- and FEW WAVES IN FLIGHT: single-wave workgroups that each reserve
+        // 22 KB of LDS they never touch, so that a CU holds 7 of them instead of 32 waves.  Thirteen streams from 8192
+        // resident waves thrash the memory system's open pages; from 1792 they do not: 2^24 envs, same box, interleaved
+        // (tools/envstep_ab.hip): 256 threads / no limit 152.5 us = 0.715 of 8 TB/s; 5 / 6 / 7 / 8 / 10 / 12 / 16 waves per CU
+        // 148.0 / 132.1 / 132.1 / 133.9 / 134.4 / 141.1 / 151.1 us -- 0.826 at 6-7, above a plain two-stream copy (0.805).
+        // ses_set_tuning "env_step_block" / "env_step_lds_bytes" (0 = the old shape: 256 threads, no reservation).
+        const EnvStepShape sh = env_step_shape(h, n4);
         if (mode == SES_MODE_FIXED_LENGTH)
-            hipLaunchKernelGGL((k_env_step_cartpole_v4<true>), dim3(blocks), dim3(256), 0, h->stream, n4, max_step,
+            hipLaunchKernelGGL((k_env_step_cartpole_v4<true>), dim3(sh.blocks), dim3(sh.block), sh.lds, h->stream, n4, max_step,
                                (f32x4 *)x, (f32x4 *)xd, (f32x4 *)th, (f32x4 *)thd, (const i32x4 *)action,
                                (f32x4 *)ret, (u32x4 *)status);
         else
-            hipLaunchKernelGGL((k_env_step_cartpole_v4<false>), dim3(blocks), dim3(256), 0, h->stream, n4, max_step,
+            hipLaunchKernelGGL((k_env_step_cartpole_v4<false>), dim3(sh.blocks), dim3(sh.block), sh.lds, h->stream, n4, max_step,
                                (f32x4 *)x, (f32x4 *)xd, (f32x4 *)th, (f32x4 *)thd, (const i32x4 *)action,
                                (f32x4 *)ret, (u32x4 *)status);
     }
@@ -1442,8 +1461,8 @@ int ses_stream_probe(ses_handle *h, int32_t n, float *x, float *xd, float *th, f
     SES_REQUIRE(n >= 4 && (n & 3) == 0 && (align & 15u) == 0, "ses_stream_probe: n must be a multiple of 4 and the arrays 16-byte aligned");
     SES_HIP_TRY(hipSetDevice(h->cfg.device));
     const int n4 = n / 4;
-    const int blocks = ceil_div(n4, 256) < (1 << 20) ? ceil_div(n4, 256) : (1 << 20);   // the env-step kernel's grid
-    hipLaunchKernelGGL(k_stream_probe13, dim3(blocks), dim3(256), 0, h->stream, n4, (f32x4 *)x, (f32x4 *)xd, (f32x4 *)th,
+    const EnvStepShape sh = env_step_shape(h, n4);                                       // the env-step kernel's launch shape
+    hipLaunchKernelGGL(k_stream_probe13, dim3(sh.blocks), dim3(sh.block), sh.lds, h->stream, n4, (f32x4 *)x, (f32x4 *)xd, (f32x4 *)th,
                        (f32x4 *)thd, (const i32x4 *)action, (f32x4 *)ret, (u32x4 *)status);
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;

@@ -177,6 +177,47 @@ __global__ __launch_bounds__(BLOCK) void k_step_oop(int n4, int max_step, const 
     st<true>(ostatus + i, vs);
 }
 
+// A plain copy with the env step's instruction mix: 7 loads and 6 stores of 16 bytes per lane, src -> dst, each workgroup a
+// contiguous chunk (tells apart "thirteen memory instructions per lane" from "thirteen address streams")
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_copy_7_6(long n_chunks, const f4v *src, f4v *dst)
+{
+    const long b = blockIdx.x;
+    if (b >= n_chunks) return;
+    const f4v *s = src + b * 7 * BLOCK;
+    f4v *d = dst + b * 6 * BLOCK;
+    f4v v[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = ld<true>(s + k * BLOCK + threadIdx.x);
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+    asm volatile("" ::"v"(v[6]));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) st<true>(d + k * BLOCK + threadIdx.x, v[k]);
+}
+
+// the product kernel with a dummy LDS allocation that limits the workgroups per CU (memory-level parallelism)
+template <int LDS_BYTES, int BLOCK = 256>
+__global__ __launch_bounds__(BLOCK) void k_step_occ(int n4, int max_step, f4v *x, f4v *xd, f4v *th, f4v *thd, const i4v *action,
+                                                  f4v *ret, u4v *status)
+{
+    __shared__ char pad[LDS_BYTES];
+    if (n4 < 0) pad[threadIdx.x] = 0;                                       // keeps the allocation
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n4) return;
+    f4v vx = ld<true>(x + i), vxd = ld<true>(xd + i), vth = ld<true>(th + i), vthd = ld<true>(thd + i), vr = ld<true>(ret + i);
+    i4v va = ld<true>(action + i);
+    u4v vs = ld<true>(status + i);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        float ex = vx[l], exd = vxd[l], eth = vth[l], ethd = vthd[l], er = vr[l];
+        uint32_t es = vs[l];
+        step_one(ex, exd, eth, ethd, va[l], er, es, max_step);
+        vx[l] = ex; vxd[l] = exd; vth[l] = eth; vthd[l] = ethd; vr[l] = er; vs[l] = es;
+    }
+    st<true>(x + i, vx); st<true>(xd + i, vxd); st<true>(th + i, vth); st<true>(thd + i, vthd); st<true>(ret + i, vr);
+    st<true>(status + i, vs);
+}
+
 // Tiled SoA: the seven arrays of G * BLOCK * 4 envs lie behind one another in one contiguous tile (7 x G x BLOCK float4
 // groups); a workgroup owns a tile.  Same 52 bytes per env-step, but a launch is one sequential read stream and one
 // sequential write stream over the allocation instead of seven + six concurrent ones.  ARITH = false: the copy ceiling.
@@ -256,7 +297,8 @@ int main(int argc, char **argv)
     std::vector<Variant> vs;
 #define ADD(NAME, GRID, BLOCK, KERNEL)                                                                                  \
     vs.push_back({NAME, [=] { hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, 0, n4, 0, x, xd, th, thd, ac, rt, stt); }, bytes, {}})
-    ADD("product: nt, 16 B/lane, one-shot, b256", n4 / 256, 256, (k_step<true, true, 1, 256, 0>));
+    vs.push_back({"PRODUCT: nt, 16 B/lane, one-shot, b64, 22 KB LDS reserved (7 waves per CU)", [=] { hipLaunchKernelGGL((k_step<true, true, 1, 64, 0>), dim3(n4 / 64), dim3(64), 22528, 0, n4, 0, x, xd, th, thd, ac, rt, stt); }, bytes, {}});
+    ADD("until round 3: nt, 16 B/lane, one-shot, b256, unlimited waves", n4 / 256, 256, (k_step<true, true, 1, 256, 0>));
     ADD("2 x 16 B/lane, one-shot, b256", n4 / 512, 256, (k_step<true, true, 2, 256, 0>));
     ADD("persistent 256 CU x 8 wg, 16 B", 2048, 256, (k_step<true, true, 1, 256, 0>));
     ADD("persistent 256 CU x 8 wg, 2 x 16 B", 2048, 256, (k_step<true, true, 2, 256, 0>));
@@ -283,6 +325,40 @@ int main(int argc, char **argv)
     u4v *ostt = (u4v *)(pool2 + 6 * stride);
     vs.push_back({"OUT OF PLACE product (second set of arrays)", [=] { hipLaunchKernelGGL((k_step_oop<true, 256>), dim3(n4 / 256), dim3(256), 0, 0, n4, 0, x, xd, th, thd, ac, rt, stt, ox, oxd, oth, othd, ort, ostt); }, bytes, {}});
     vs.push_back({"CEILING out-of-place copy13", [=] { hipLaunchKernelGGL((k_step_oop<false, 256>), dim3(n4 / 256), dim3(256), 0, 0, n4, 0, x, xd, th, thd, ac, rt, stt, ox, oxd, oth, othd, ort, ostt); }, bytes, {}});
+    {
+        f4v *s7, *d6;
+        CK(hipMalloc(&s7, (size_t)n * 28));
+        CK(hipMalloc(&d6, (size_t)n * 24));
+        CK(hipMemset(s7, 1, (size_t)n * 28));
+        const long chunks = n4 / 256;
+        vs.push_back({"CEILING copy 7 loads + 6 stores per lane, chunks", [=] { hipLaunchKernelGGL((k_copy_7_6<256>), dim3((unsigned)chunks), dim3(256), 0, 0, chunks, (const f4v *)s7, d6); }, bytes, {}});
+    }
+    ADD("product, 40 KB LDS pad (4 wg per CU)", n4 / 256, 256, (k_step_occ<40960>));
+    ADD("product, 20 KB LDS pad (8 wg per CU)", n4 / 256, 256, (k_step_occ<20480>));
+    ADD("product, 64 KB LDS pad (2 wg per CU)", n4 / 256, 256, (k_step_occ<65536>));
+    ADD("product, 53 KB LDS pad (3 wg per CU)", n4 / 256, 256, (k_step_occ<54272>));
+    ADD("product, 64 KB pad, b128 (2 wg = 4 waves per CU)", n4 / 128, 128, (k_step_occ<65536, 128>));
+    ADD("product, 64 KB pad, b64 (2 wg = 2 waves per CU)", n4 / 64, 64, (k_step_occ<65536, 64>));
+    ADD("product, 64 KB pad, b512 (2 wg = 16 waves per CU)", n4 / 512, 512, (k_step_occ<65536, 512>));
+    ADD("product, 64 KB pad, b1024 (2 wg = 32 waves/CU)", n4 / 1024, 1024, (k_step_occ<65536, 1024>));
+    ADD("product, 40 KB pad, b128 (4 wg = 8 waves per CU)", n4 / 128, 128, (k_step_occ<40960, 128>));
+    ADD("product, 20 KB pad, b64 (8 wg = 8 waves per CU)", n4 / 64, 64, (k_step_occ<20480, 64>));
+    // occupancy by dynamic LDS (nothing in the kernel reads it): workgroups per CU = 160 KB / bytes
+#define ADDL(NAME, BLOCK, LDS)                                                                                          \
+    vs.push_back({NAME, [=] { hipLaunchKernelGGL((k_step<true, true, 1, BLOCK, 0>), dim3(n4 / BLOCK), dim3(BLOCK), LDS, 0, n4, 0, x, xd, th, thd, ac, rt, stt); }, bytes, {}})
+    ADDL("dyn LDS: b64, 32 KB (5 waves per CU)", 64, 32768);
+    ADDL("dyn LDS: b64, 26 KB (6 waves per CU)", 64, 26624);
+    ADDL("dyn LDS: b64, 22.8 KB (7 waves per CU)", 64, 23296);
+    ADDL("dyn LDS: b64, 20 KB (8 waves per CU)", 64, 20480);
+    ADDL("dyn LDS: b64, 17.7 KB (9 waves per CU)", 64, 18176);
+    ADDL("dyn LDS: b64, 16 KB (10 waves per CU)", 64, 16384);
+    ADDL("dyn LDS: b64, 13.3 KB (12 waves per CU)", 64, 13568);
+    ADDL("dyn LDS: b64, 10 KB (16 waves per CU)", 64, 10240);
+    ADDL("dyn LDS: b128, 40 KB (4 wg = 8 waves)", 128, 40960);
+    ADDL("dyn LDS: b128, 32 KB (5 wg = 10 waves)", 128, 32768);
+    ADDL("dyn LDS: b256, 64 KB (2 wg = 8 waves)", 256, 65536);
+    vs.push_back({"dyn LDS: out of place b64, 20 KB (8 waves)", [=] { hipLaunchKernelGGL((k_step_oop<true, 64>), dim3(n4 / 64), dim3(64), 20480, 0, n4, 0, x, xd, th, thd, ac, rt, stt, ox, oxd, oth, othd, ort, ostt); }, bytes, {}});
+    vs.push_back({"dyn LDS: CEILING copy13 b64, 20 KB (8 waves)", [=] { hipLaunchKernelGGL((k_copy13<true, 1, 64>), dim3(n4 / 64), dim3(64), 20480, 0, n4, 0, x, xd, th, thd, ac, rt, stt); }, bytes, {}});
     // tiled layout: one allocation of n / tile_envs tiles
     f4v *tiles;
     CK(hipMalloc(&tiles, (size_t)n * 28));
@@ -319,12 +395,12 @@ int main(int argc, char **argv)
     }
     CK(hipGetLastError());
     printf("n = 2^%d envs, %.1f MB per launch, %d rounds x %d launches, pre-roll %d\n", lg, bytes / 1e6, rounds, launches, preroll);
-    printf("%-46s %9s %9s %9s %9s %8s\n", "variant", "med us", "min us", "max us", "med GB/s", "frac 8T");
+    printf("%-64s %9s %9s %9s %9s %8s\n", "variant", "med us", "min us", "max us", "med GB/s", "frac 8T");
     for (auto &v : vs) {
         std::vector<float> s = v.us;
         std::sort(s.begin(), s.end());
         const float med = s[s.size() / 2];
-        printf("%-46s %9.2f %9.2f %9.2f %9.1f %8.4f\n", v.name.c_str(), med, s.front(), s.back(), v.bytes / med / 1e3,
+        printf("%-64s %9.2f %9.2f %9.2f %9.1f %8.4f\n", v.name.c_str(), med, s.front(), s.back(), v.bytes / med / 1e3,
                v.bytes / med / 1e3 / 8000.0);
     }
     return 0;

@@ -29,7 +29,7 @@ python tools/timeline_gaps.py $(find gpurun_out/prof_kt -name "*kernel_trace.csv
 rm -f gpurun_out/fuzz_[0-9]*.txt
 bash tools/fuzz_round.sh $FUZZ 300 > $OUT/${TAG}_fuzz_parity.txt 2>&1; tail -1 $OUT/${TAG}_fuzz_parity.txt | cut -c1-300
 grep -h MISMATCH gpurun_out/fuzz_[0-9]*.txt | head -5
-[ -x tools/envstep_ab ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -I simple-es_amd/csrc tools/envstep_ab.hip -o tools/envstep_ab
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -I simple-es_amd/csrc tools/envstep_ab.hip -o tools/envstep_ab
 tools/envstep_ab 24 15 20 200 > $OUT/${TAG}_envstep_ab_final_box.txt 2>&1; head -3 $OUT/${TAG}_envstep_ab_final_box.txt
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 python bench.py --gru --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_gru.json 2>> $OUT/bench.err
