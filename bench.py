@@ -166,12 +166,12 @@ def env_step_roofline(es, n_env, launches=20, batches=15, preroll=200):
     # rounds 1-3a): what limiting the waves in flight is worth on this box
     es.set_tuning("env_step_block", 256)
     es.set_tuning("env_step_lds_bytes", 0)
-    for _ in range(20):
+    for _ in range(5):
         step()
     wide_steps, wide_probes = [], []
-    for _ in range(5):
-        wide_steps.append(batch(step, launches))
-        wide_probes.append(batch(probe, launches))
+    for _ in range(3):                                   # (few launches: they share the kernel's name in a rocprofv3 trace)
+        wide_steps.append(batch(step, 10))
+        wide_probes.append(batch(probe, 10))
     es.set_tuning("env_step_block", 64)
     es.set_tuning("env_step_lds_bytes", 22528)
     # torch's device-to-device copy of the same byte count (read half, write half: two streams)
