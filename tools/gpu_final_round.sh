@@ -22,7 +22,7 @@ python tools/collect_sq.py $TAG gru_mfma k_rollout_gru_mfma gpurun_out/mf_1 gpur
 python tools/collect_sq.py $TAG box2d_mlp k_rollout_box2d_mlp gpurun_out/sqb2_1 gpurun_out/sqb2_2
 cp profiles/${TAG}_pmc_env_step.json profiles/${TAG}_sq_*.json $OUT/
 cp gpurun_out/kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
-tail -1 gpurun_out/prof_kt_bench.log > $OUT/${TAG}_bench_profiled.json
+grep "^{\"metric\"" gpurun_out/prof_kt_bench.log | tail -1 > $OUT/${TAG}_bench_profiled.json
 cp gpurun_out/pmc_stdout.txt $OUT/${TAG}_pmc_stdout.txt
 cp gpurun_out/configs.jsonl $OUT/${TAG}_configs.jsonl
 python tools/timeline_gaps.py $(find gpurun_out/prof_kt -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_generation_timeline.txt 2>&1
