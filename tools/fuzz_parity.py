@@ -158,6 +158,7 @@ def main():
             pomdp = bool(rng.randint(0, 2))
             es = HipES("LunarLanderContinuous-v2", 8, 4, False, gru, pomdp=pomdp, max_step=T, eval_ep_num=E)
             es.set_tuning("box2d_lanes_per_env", int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64])))     # MLP kernel only
+            es.set_tuning("box2d_envs_per_wave", int(rng.choice([0, 0, 1, 3, 5, 10, 20, 33, 64])))  # (clamped to 64 / lanes per env)
             if gru and rng.rand() < 0.6:                                 # every GRU lander kernel: lockstep (1, 2, 4 offspring per wave), MFMA, sequential
                 es.set_tuning("gru_ep_parallel_max", 0)
                 es.set_tuning("lander_offspring_per_wave", int(rng.choice([0, 1, 2, 4])))
@@ -176,6 +177,7 @@ def main():
             n, E, T = int(rng.choice([1, 5, 17])), int(rng.choice([1, 2, 5])), int(rng.choice([5, 40, 90]))     # time-boxed: the oracle's walker step is ~1 ms
             es = HipES("BipedalWalker-v3", 24, 4, False, False, max_step=T, eval_ep_num=E)
             es.set_tuning("box2d_lanes_per_env", int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64])))
+            es.set_tuning("box2d_envs_per_wave", int(rng.choice([0, 0, 1, 3, 5, 10, 20, 33, 64])))
             theta = (rng.randn(n, es.P) * sigma).astype(np.float32)
             init = rng.uniform(0, 1, (E, 4) if shared else (n, E, 4)).astype(np.float32)
             ref = co.rollout_walker(theta, init, E, T)
