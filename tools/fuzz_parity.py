@@ -112,6 +112,7 @@ def main():
     args = ap.parse_args()
     import time
     t_start = time.time()
+    t_progress = t_start
     rng = np.random.RandomState(args.seed)
     tally = {}
     done_cases = 0
@@ -201,6 +202,10 @@ def main():
         t = tally.setdefault(kind, [0, 0])
         t[0] += 1
         t[1] += int(ok)
+        if time.time() - t_progress > 60.0:                              # a sign of life for long passes (gpurun's silence guard)
+            t_progress = time.time()
+            print("progress", json.dumps({"cases": done_cases, "seconds": round(t_progress - t_start, 1),
+                                          "all_bit_exact": all(v[0] == v[1] for v in tally.values())}), flush=True)
         if not ok:
             print("MISMATCH", json.dumps({"case": case, "kind": kind, "n": n, "E": E, "mode": mode, "shared": shared, "sigma": sigma}))
     print(json.dumps({"cases": done_cases, "seed": args.seed, "seconds": round(time.time() - t_start, 1), "by_kind": {k: {"cases": v[0], "bit_exact": v[1]} for k, v in tally.items()},
