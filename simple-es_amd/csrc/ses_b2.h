@@ -891,6 +891,8 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
         velocity_iteration<D, REPACK>(body, joint, jt, rare, mc, ct, any_contact);
     };
     if constexpr (D::VEL_FIXED_POINT_CHECK < 0) {
+        // (the body of velocity_iteration written out: through the helper the walker's loop comes out of hipcc with a third
+        //  more AGPR moves -- 392 instead of 296 -- for the same source)
         for (int it = 0; it < D::VEL_ITERS; ++it) {
             B2_UNROLL
             for (int j = 0; j < D::NJ; ++j) joint_solve_velocity<D>(body, joint, j, jt[j], rare);
