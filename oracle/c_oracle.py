@@ -24,8 +24,23 @@ def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".cpp", ".h"))]
     srcs += [os.path.join(world, f) for f in ("ses_b2.h", "ses_b2_toi.h", "ses_b2_shapes.h", "ses_lander_env.h", "ses_walker_env.h")]
     src_m = max(os.path.getmtime(f) for f in srcs)
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m:
-        subprocess.check_call(["make", "-s", "-C", _HERE])
+
+    def stale():
+        return not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m
+
+    if force or stale():
+        # One builder at a time: the bench's CPU-baseline pool has a worker per host core, each of which gets here when the
+        # library is older than a source (256 concurrent `make`s over one _build/ once left half-written objects, workers
+        # that died loading them, and a Pool.map that waited for ever).  The others wait for the lock and find it built.
+        import fcntl
+        os.makedirs(os.path.dirname(_SO), exist_ok=True)
+        with open(os.path.join(os.path.dirname(_SO), ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if force or stale():
+                    subprocess.check_call(["make", "-s", "-C", _HERE])
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return _SO
 
 

@@ -87,12 +87,20 @@ def run_generation(theta, init_states, episodes, max_step, process_num, fixed_le
     cls = FixedLengthCartPole if fixed_length else CartPoleF32Env
     env = cls(init_states, max_step=max_step, pomdp=pomdp)
     tasks = [(env, net_cfg, theta[i], episodes) for i in range(theta.shape[0])]
+    from . import c_oracle
+    c_oracle.lib()                                       # built and loaded BEFORE the fork: no worker builds anything
     t0 = time.perf_counter()
     if process_num > 1:
         pool = mp.Pool(process_num)
-        out = pool.map(rollout_worker, tasks)
-        pool.close()
-        pool.join()
+        try:
+            # a worker that dies takes its task with it and map() would wait for ever: bounded instead
+            out = pool.map_async(rollout_worker, tasks).get(timeout=600)
+            pool.close()
+        except BaseException:
+            pool.terminate()
+            raise
+        finally:
+            pool.join()
     else:
         out = [rollout_worker(t) for t in tasks]
     dt = time.perf_counter() - t0
