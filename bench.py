@@ -569,6 +569,36 @@ def run_rank(args):
                 c3.close()
             except Exception as exc:
                 result["c3_error"] = repr(exc)
+        # conf/bipedalwalker.yaml and conf/lunarlander.yaml at 4096 offspring x 5 episodes x <= 300 steps (MLP policies on the
+        # Box2D-style world, continuous collision on): one warm rollout, the median of two
+        if not args.no_extras and not args.gru and world == 1:
+            try:
+                from ses import HipES
+                legs = {}
+                for key, name, S in (("bipedalwalker_ms", "BipedalWalker-v3", 24), ("lunarlander_ms", "LunarLanderContinuous-v2", 8)):
+                    bx = HipES(name, S, 4, False, False, max_step=300, eval_ep_num=5)
+                    th = bx.perturb(bx.zeros(bx.P), 2.0, 0, 0, 0, 4096)
+                    ini = bx.init_states_uniform(0, 0, 0, 4096)
+                    fitb = bx.empty(4096)
+                    bx.rollout(th, ini, fitness=fitb)
+                    torch.cuda.synchronize()
+                    tb = []
+                    for _ in range(2):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        bx.rollout(th, ini, fitness=fitb)
+                        e1.record()
+                        e1.synchronize()
+                        tb.append(e0.elapsed_time(e1))
+                    _, _, stb = bx.rollout(th, ini, want_episodes=True)
+                    legs[key] = statistics.median(tb)
+                    legs[key.replace("_ms", "_env_steps")] = int(stb.sum().item())
+                    bx.close()
+                legs["note"] = ("first-generation policies (sigma 2.0 around the zero network); parity with gym / Box2D unpinned, "
+                                "GPU == CPU build bit for bit; round 2: 455 / 42 ms")
+                result["box2d_mlp_4096"] = legs
+            except Exception as exc:
+                result["box2d_mlp_error"] = repr(exc)
         if not args.no_roofline:
             try:
                 result["roofline"] = env_step_roofline(es, args.roofline_envs)
