@@ -27,6 +27,7 @@ each with the transport of the all-gather, its time and the per-rank fitness-loo
 Extra legs (rank 0): `roofline` -- the standalone SoA env-step kernel at 2^24 envs against the HBM roof
 (SURVEY 8d: 52 algorithmic bytes per env-step), timed with HIP events on the launch stream;
 `loop_ms_per_generation` -- ESLoop.run() itself, prints and metrics included;
+`c3_lunarlander_pomdp_gru_4096` / `box2d_mlp_4096` -- one rollout of BASELINE configs[2] and of the Box2D MLP configs (N = 1);
 `cpu_baseline` -- the reference-structured Python multiprocessing port on the host cores (N = 1 only).
 """
 import os
