@@ -229,6 +229,31 @@ def test_env_step_wild_states_general_sincos_and_angle_clamp(es, mode):
         assert np.abs(st[2]).max() == np.float32(0.75)           # the clamp was active
 
 
+@pytest.mark.parametrize("block,lds", [(256, 0), (128, 40960), (64, 10240), (256, 65536)])
+def test_env_step_launch_shapes_change_no_bit(block, lds):
+    """ses_env_step limits its waves in flight with an LDS reservation (knobs env_step_block / env_step_lds_bytes): every
+    shape, the old unlimited one included, returns the bits of the default one -- and of the oracle."""
+    from ses import HipES
+    n = 70000 + 4 * 37                                            # several workgroups of every shape, a ragged tail
+    rng = np.random.RandomState(block + lds)
+    st = [rng.uniform(-0.3, 0.3, n).astype(np.float32) for _ in range(4)]
+    ret, status = np.zeros(n, np.float32), np.zeros(n, np.uint32)
+    h = HipES("CartPole-v1", 4, 2, True, False, max_step=500, eval_ep_num=1)
+    h.set_tuning("env_step_block", block)
+    h.set_tuning("env_step_lds_bytes", lds)
+    d = [dev(a) for a in st]
+    d_ret, d_status = dev(ret), dev(status.view(np.int32))
+    for t in range(5):
+        action = rng.randint(0, 2, n).astype(np.int32)
+        co.cartpole_step_soa(1, 500, st[0], st[1], st[2], st[3], action, ret, status)
+        h.env_step(d[0], d[1], d[2], d[3], dev(action), d_ret, d_status, mode=1)
+    for k in range(4):
+        assert_bit_equal(host(d[k]), st[k], f"state[{k}]")
+    assert_bit_equal(host(d_ret), ret, "ret")
+    assert np.array_equal(host(d_status).view(np.uint32), status)
+    h.close()
+
+
 def test_env_step_unaligned_views_take_scalar_path(es):
     n = 1001
     rng = np.random.RandomState(3)
