@@ -20,13 +20,18 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("n,E,T,lpe", [(1, 1, 40, 0), (37, 3, 150, 0), (37, 3, 150, 8), (37, 3, 150, 4), (37, 3, 150, 2), (37, 3, 150, 1), (37, 3, 150, 32)])
-def test_walker_population_bit_exact(n, E, T, lpe):
-    """lpe: lanes per env of the rollout kernel (0 = the library's choice, 8 at this size); 1 and 2 stream the weights."""
+@pytest.mark.parametrize("n,E,T,lpe,epw", [(1, 1, 40, 0, 0), (37, 3, 150, 0, 0), (37, 3, 150, 8, 0), (37, 3, 150, 4, 0), (37, 3, 150, 2, 0),
+                                           (37, 3, 150, 1, 0), (37, 3, 150, 32, 0), (37, 3, 150, 2, 20), (37, 3, 150, 0, 7), (37, 3, 150, 4, 3),
+                                           (37, 3, 150, 1, 64), (37, 3, 150, 16, 9)])
+def test_walker_population_bit_exact(n, E, T, lpe, epw):
+    """lpe: lanes per env of the rollout kernel (0 = the library's choice); 1 and 2 stream the weights.  epw: different envs
+    per wave (0 = 64 / lpe or, with lpe = 0, as few as the wave slots allow; the lane groups past the last env shadow it;
+    values beyond 64 / lpe are clamped)."""
     from ses import HipES
     rng = np.random.RandomState(n)
     es = HipES("BipedalWalker-v3", 24, 4, False, False, max_step=T, eval_ep_num=E)
     es.set_tuning("box2d_lanes_per_env", lpe)
+    es.set_tuning("box2d_envs_per_wave", epw)
     assert es.P == 932
     theta = (rng.randn(n, es.P) * rng.choice([0.1, 0.5, 2.0], size=(n, 1))).astype(np.float32)
     init = es.init_states_uniform(3, 1, 20, n)                          # [n, E, 4] uniforms in [0,1)
