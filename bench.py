@@ -256,10 +256,10 @@ class Job:
         self.pop = strat.init_offspring(self.loop.network, self.loop.env.get_agent_ids())
 
     def generations(self, k):
-        loop, pop = self.loop, self.pop
-        for _ in range(k):
-            pop, _best, _sigma, _ev = loop.generation(pop)
-        self.pop = pop
+        # ESLoop.generations: k generations enqueued the way ESLoop.run() enqueues them -- through ses_run_generations in
+        # chunks of <= 32 (on several GPUs with the fitness all-gather issued by the C loop), or k x ESLoop.generation()
+        # where the run is not eligible for it (SES_BATCH_GENERATIONS=0, no library transport between the ranks)
+        self.pop = self.loop.generations(self.pop, k)
 
     def steps_per_generation(self):
         return self.n_global * self.E * self.T
@@ -378,7 +378,10 @@ def run_rank(args):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("POMDP CartPole-v1 openai_es GRU(4-32-GRU32-2, P=6562)" if args.gru else
                                 "CartPole-v1 openai_es MLP(4-32-2, P=226)") + ", fixed-length episodes, termination masked",
-                   "timed_call": "ESLoop.generation() x steps (the product loop's own method), openai_es strategy object",
+                   "timed_call": ("ESLoop.generations(steps): the product loop's own enqueue path -- ses_run_generations in chunks of <= 32 "
+                                  "generations, the fitness all-gather issued by the C loop" if job.loop.batched_generations or
+                                  getattr(job.loop, "_bench_batch", None) else
+                                  "ESLoop.generation() x steps (the product loop's per-generation method), openai_es strategy object"),
                    "offspring_per_gpu": args.offspring_per_gpu, "offspring_total": job.n_global, "eval_ep_num": E,
                    "max_step": T, "env_steps_per_generation": job.steps_per_generation(),
                    "noise": "rocRAND philox4x32_10", "preroll_generations": preroll,

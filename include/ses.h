@@ -98,7 +98,8 @@ int ses_sync(ses_handle *h);
  * populations of up to k * 1024 rows), "comm_force_rccl" (1: ses_allgather_fitness uses the RCCL communicator although the
  * peer-store transport is attached -- for measuring one against the other), "comm_p2p_timeout_ms" (how long a peer-store
  * exchange waits for a peer's shard; 0 = default 60000), "comm_p2p_keep_going" (1: after a time-out later exchanges still
- * run instead of failing; the host polls ses_comm_p2p_status, agrees with the other ranks and rolls back -- ESLoop.run()).
+ * run instead of failing; the host polls ses_comm_p2p_status, agrees with the other ranks and rolls back -- ESLoop.run()),
+ * "openai_sharded_tail" (default 1; 0: ses_openai_sharded_ok answers no, sharded runs keep the replicated openai_es tail).
  * The library itself reads no environment variable. */
 int ses_set_tuning(ses_handle *h, const char *name, int32_t value);
 /* Timing without events: from now on the last kernel of every ses_rollout (the episode mean: end of the rollout phase)
@@ -233,6 +234,22 @@ int ses_openai_generation(ses_handle *h, const float *fitness, int32_t n, uint64
                           double sigma, double adam_a, const float *mu_in, const float *m_in, const float *v_in,
                           float *mu_out, float *m_out, float *v_out, float next_sigma, uint64_t next_gen,
                           int64_t first_row, int32_t n_rows, float *theta_next, float *best);
+/* The same generation when the population is sharded over `world` ranks (loop.py:66-84 with one process per GPU) WITHOUT
+ * every rank repeating the O(n) work: this rank ranks only its own rows [first_row, first_row + n_rows) against the gathered
+ * fitness (n <= 8192: counting rank; above: every workgroup sorts one 1024-key tile and searches it for 1024 own rows) and
+ * accumulates the ES gradient over its own 1024-row chunks only; the ranks then all-gather their [chunks per rank, P] chunk
+ * partials -- with the candidates for max(fitness) behind them -- through `comm`'s transport (ses_allgather_fitness: peer
+ * stores or RCCL; 58 KB in total at 65 536 x 226), and the unchanged ordered update adds the chunks in ascending order.
+ * Bit-identical to ses_openai_generation for ANY world size, because a rank's slot of per_rank = ceil(n / world) rows is a
+ * whole number of the gradient's 1024-row chunks -- that is the condition; ses_openai_sharded_ok tells (1 / 0) whether it
+ * holds and `comm` (a handle on the same device and stream that owns a transport of `world` ranks which takes the payload)
+ * can carry it.  Otherwise: SES_ERR_UNSUPPORTED, use ses_openai_generation.  Collective: every rank calls it. */
+int ses_openai_sharded_ok(ses_handle *h, ses_handle *comm, int32_t n, int32_t per_rank, int32_t world);
+int ses_openai_generation_sharded(ses_handle *h, ses_handle *comm, const float *fitness, int32_t n, uint64_t seed, uint64_t gen,
+                                  double lr, double sigma, double adam_a, const float *mu_in, const float *m_in,
+                                  const float *v_in, float *mu_out, float *m_out, float *v_out, float next_sigma,
+                                  uint64_t next_gen, int64_t first_row, int32_t n_rows, int32_t per_rank, int32_t world,
+                                  float *theta_next, float *best);
 /*
  * grad = (-lr / (n*sigma)) * sum_i weights[i] * eps_i ;  Adam (beta1 = 0.99, beta2 = 0.999, eps = 1e-8)
  * with step scale adam_a = lr*sqrt(1-beta2^t)/(1-beta1^t) computed by the host; mu, m, v updated in place.
@@ -279,7 +296,11 @@ int ses_gather_rows(ses_handle *h, const float *src, const int32_t *ids, int32_t
  * scalars (sigma decay, Adam's step scale, generation keys) advanced exactly as the Python classes advance them, so the
  * results are bit-identical to k per-generation calls.  Why: a generation of the reference's own configs (96-240
  * offspring) is 60-120 us of kernels and took ~96 us of Python to enqueue; from C the device is the limit.
- * Single process (no all-gather inside); counter-based noise only.  Everything is enqueued, nothing is waited for.
+ * Counter-based noise only.  Everything is enqueued, nothing is waited for.
+ * Sharded runs (world > 1, one process per GPU): the rollout covers this rank's n_local rows, ses_allgather_fitness on `comm`
+ * (the handle that owns the transports; same device and stream) gathers the shards inside the loop, openai_es continues
+ * with ses_openai_generation_sharded where ses_openai_sharded_ok allows it, everything else with the replicated tail over
+ * all n rows.  A peer-store time-out is the caller's to poll (ses_comm_p2p_status) at its own boundaries.
  *
  * ses_gen_state: the caller fills the fixed part and the buffers once, the call advances the rest in place:
  *   strategy            SES_STRATEGY_*
@@ -289,7 +310,12 @@ int ses_gather_rows(ses_handle *h, const float *src, const int32_t *ids, int32_t
  *                       parents: mu[P] (openai_es, simple_evolution) or elites[elite_num, P] (simple_genetic)
  *   parent_map          int32[n] on the device, the strategy's constant map as for ses_perturb (elite strategies)
  *   alias_state         int32[1] on the device (simple_evolution, see ses_elite_select)
- *   fitness[n], init[(shared_init ? 1 : n) * E * init_width], work_i32[n + 3 * elite_num], work_f32[elite_num * P]
+ *   fitness[n] (sharded: [world * per_rank], the gathered vector), init[(shared_init ? 1 : rows of theta) * E * init_width],
+ *   work_i32[n + 3 * elite_num], work_f32[elite_num * P]
+ *   world, first_row, n_local, per_rank, comm, fit_local   sharded runs only (world <= 1: ignored): this rank owns the global
+ *                       rows [first_row, first_row + n_local) with first_row = rank * per_rank, per_rank = ceil(n / world);
+ *                       theta[] then has n_local rows; fit_local[per_rank] receives this rank's fitness, its tail
+ *                       [n_local, per_rank) holds -inf, written once by the caller
  *   sigma / pop_sigma   curr_sigma of the strategy / the sigma the current population was drawn with
  *   pop_gen             generation key of the current population (its noise and its env resets)
  *   adam_t              Adam's step counter
@@ -308,7 +334,7 @@ typedef struct ses_gen_state {
     double sigma, pop_sigma;
     uint64_t pop_gen;
     int64_t adam_t;
-    int32_t cur, reserved;
+    int32_t cur, world;
     float *theta[2];
     float *parents[2];
     float *adam_m[2];
@@ -319,6 +345,10 @@ typedef struct ses_gen_state {
     float *init;
     int32_t *work_i32;
     float *work_f32;
+    int64_t first_row;
+    int32_t n_local, per_rank;
+    ses_handle *comm;
+    float *fit_local;
 } ses_gen_state;
 int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best, uint64_t *stamps);
 
@@ -361,6 +391,13 @@ int ses_allgather_fitness(ses_handle *h, const float *local, int32_t n_per_rank,
 #define SES_COMM_P2P_HANDLE_BYTES 64
 int ses_comm_p2p_export(ses_handle *h, int32_t rank, int32_t world, int32_t max_per_rank, void *handle);
 int ses_comm_p2p_attach(ses_handle *h, const void *handles);
+/* The same transport between handles of ONE process (a host that drives several GPUs, or several streams of one GPU, from
+ * one process; also how one test process forms worlds of 8 and 16 ranks on a single GPU): every handle exports as above, then
+ * attaches the peers' HANDLES -- peers[world] in rank order, peers[rank] == h -- instead of their IPC bytes: nothing is
+ * mapped, the peers' mailboxes are addressed directly, so they must live on the same device or on devices the caller has
+ * enabled peer access between, each handle needs a stream of its own (an exchange kernel waits for its peers' kernels), and
+ * every handle must detach before any of them is destroyed. */
+int ses_comm_p2p_attach_local(ses_handle *h, ses_handle *const *peers);
 int ses_comm_p2p_info(ses_handle *h, int32_t *world, int32_t *max_per_rank, int32_t *exchanges);
 int ses_comm_p2p_status(ses_handle *h, uint32_t *timed_out_mask);   /* bit r: an exchange gave up waiting for rank r */
 int ses_comm_p2p_detach(ses_handle *h);

@@ -59,12 +59,15 @@ constexpr unsigned long long P2P_TICKS_PER_MS = 100000ull;       // the real-tim
 struct ses_p2p {
     int rank, world, max_per_rank, splits_max;
     bool attached;
-    size_t bytes, flag_offset;              // mailbox layout: float data[2][world][max_per_rank] | uint32 flags[2][world][splits_max]
+    bool local;                             // attached to handles of this process (ses_comm_p2p_attach_local): nothing mapped, nothing to close
+    size_t bytes, flag_offset;              // mailbox layout: float data[2][world][max_per_rank] | uint32 flags[2][world][splits_max] | seen mask
     void *own;                              // this rank's mailbox (device memory, fine-grained)
     void *peer[ses::P2P_MAX_WORLD];         // peer[r]: rank r's mailbox as mapped here (peer[rank] == own)
     uint32_t seq;                           // exchanges issued so far
     uint32_t *err_host;                     // pinned host word set by a kernel that timed out
     uint32_t *err_dev;                      // its device alias
+    uint32_t *err_seen;                     // the same mask in this rank's own device memory (behind the flags of the mailbox): what
+                                            // the exchange kernel reads to know that a peer has already cost it a time-out
     unsigned long long timeout_ticks;       // how long a workgroup waits for a peer's sequence word
 };
 
@@ -84,9 +87,13 @@ constexpr int P2P_SPLIT = 4096;          // floats one workgroup moves; a shard 
 __global__ __launch_bounds__(256) void k_allgather_p2p(const float *__restrict__ local, int n, int max_per_rank, int splits_max,
                                                        int rank, int world, uint32_t seq, P2pPeers peers,
                                                        float *__restrict__ out, uint32_t *err, int vec4,
-                                                       unsigned long long timeout_ticks)
+                                                       unsigned long long timeout_ticks, uint32_t *err_seen)
 {
     const int b = blockIdx.x, sp = blockIdx.y, slot = (int)(seq & 1u);
+    // a peer that has already cost this rank a time-out is waited for 2 ms at most from then on (a stalled peer would
+    // otherwise cost every later exchange the full time-out until the host's next recovery boundary); the mask is read from
+    // device memory, early, so that its latency hides behind the stores
+    const uint32_t seen = threadIdx.x == 0 ? __hip_atomic_load(err_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     const int i0 = sp * P2P_SPLIT, i1 = i0 + P2P_SPLIT < n ? i0 + P2P_SPLIT : n;
     float *dst = peers.data[b] + ((size_t)slot * world + rank) * max_per_rank;
     if (vec4) {
@@ -104,6 +111,8 @@ __global__ __launch_bounds__(256) void k_allgather_p2p(const float *__restrict__
     if (threadIdx.x == 0) {
         const uint32_t *flag = peers.flags[rank] + ((size_t)slot * world + b) * splits_max + sp;
         const unsigned long long t0 = real_time();
+        const unsigned long long short_ticks = 2ull * P2P_TICKS_PER_MS;
+        if (((seen >> (b & 31)) & 1u) && timeout_ticks > short_ticks) timeout_ticks = short_ticks;
         int good = 1;
         for (;;) {
             const uint32_t f = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -114,7 +123,10 @@ __global__ __launch_bounds__(256) void k_allgather_p2p(const float *__restrict__
             __builtin_amdgcn_s_sleep(4);
         }
         ok = good;
-        if (!good) atomicOr_system(err, 1u << (b & 31));
+        if (!good) {
+            atomicOr_system(err, 1u << (b & 31));
+            atomicOr(err_seen, 1u << (b & 31));
+        }
     }
     __syncthreads();
     const float *src = peers.data[rank] + ((size_t)slot * world + b) * max_per_rank;
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(256) void k_allgather_p2p(const float *__restrict__
 static void p2p_free(ses_p2p *p)
 {
     if (!p) return;
-    for (int r = 0; r < p->world && p->attached; ++r)
+    for (int r = 0; r < p->world && p->attached && !p->local; ++r)
         if (r != p->rank && p->peer[r]) (void)hipIpcCloseMemHandle(p->peer[r]);
     if (p->own) (void)hipFree(p->own);
     if (p->err_host) (void)hipHostFree(p->err_host);
@@ -268,7 +280,8 @@ int ses_comm_p2p_export(ses_handle *h, int32_t rank, int32_t world, int32_t max_
     p->max_per_rank = (max_per_rank + 3) / 4 * 4;                     // slots stay 16-byte aligned
     p->splits_max = ceil_div(p->max_per_rank, P2P_SPLIT);
     p->flag_offset = (sizeof(float) * 2 * (size_t)world * p->max_per_rank + 255) / 256 * 256;
-    p->bytes = p->flag_offset + sizeof(uint32_t) * 2 * (size_t)world * p->splits_max;
+    const size_t seen_offset = (p->flag_offset + sizeof(uint32_t) * 2 * (size_t)world * p->splits_max + 255) / 256 * 256;
+    p->bytes = seen_offset + 256;
     hipError_t e = hipExtMallocWithFlags(&p->own, p->bytes, hipDeviceMallocUncached);
     if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p->own, p->bytes, hipDeviceMallocFinegrained); }
     if (e != hipSuccess) {
@@ -288,6 +301,7 @@ int ses_comm_p2p_export(ses_handle *h, int32_t rank, int32_t world, int32_t max_
     std::memset(handle, 0, SES_COMM_P2P_HANDLE_BYTES);
     std::memcpy(handle, &ipc, sizeof ipc);
     p->peer[rank] = p->own;
+    p->err_seen = (uint32_t *)((char *)p->own + seen_offset);
     h->p2p = p;
     return SES_OK;
 }
@@ -312,6 +326,25 @@ int ses_comm_p2p_attach(ses_handle *h, const void *handles)
         }
     }
     p->attached = true;
+    return SES_OK;
+}
+
+int ses_comm_p2p_attach_local(ses_handle *h, ses_handle *const *peers)
+{
+    using namespace ses;
+    SES_REQUIRE(h && peers, "ses_comm_p2p_attach_local: null argument");
+    SES_REQUIRE(h->p2p && !h->p2p->attached, "ses_comm_p2p_attach_local: export a mailbox first (once)");
+    ses_p2p *p = h->p2p;
+    SES_REQUIRE(peers[p->rank] == h, "ses_comm_p2p_attach_local: peers[%d] must be this handle", p->rank);
+    for (int r = 0; r < p->world; ++r) {
+        const ses_handle *q = peers[r];
+        SES_REQUIRE(q && q->p2p && q->p2p->own && q->p2p->rank == r && q->p2p->world == p->world &&
+                        q->p2p->max_per_rank == p->max_per_rank,
+                    "ses_comm_p2p_attach_local: peers[%d] has not exported a mailbox of the same shape as rank %d of %d", r, r, p->world);
+    }
+    for (int r = 0; r < p->world; ++r) p->peer[r] = peers[r]->p2p->own;
+    p->attached = true;
+    p->local = true;
     return SES_OK;
 }
 
@@ -367,7 +400,7 @@ int ses_allgather_fitness(ses_handle *h, const float *local, int32_t n_per_rank,
         const int vec4 = (n_per_rank % 4 == 0) && ((uintptr_t)local % 16 == 0) && ((uintptr_t)all % 16 == 0);
         hipLaunchKernelGGL(k_allgather_p2p, dim3(p->world, ceil_div(n_per_rank, P2P_SPLIT)), dim3(256), 0, h->stream, local,
                            (int)n_per_rank, p->max_per_rank, p->splits_max, p->rank, p->world, p->seq, peers, all, p->err_dev, vec4,
-                           p->timeout_ticks);
+                           p->timeout_ticks, p->err_seen);
         SES_HIP_TRY(hipGetLastError());
         return SES_OK;
     }

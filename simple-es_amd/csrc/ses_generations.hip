@@ -33,14 +33,31 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
                         st->work_f32, "ses_run_generations: elite strategies need elite_num, parent_map and the work buffers");
         SES_REQUIRE(st->strategy != SES_STRATEGY_SIMPLE_EVOLUTION || st->alias_state, "ses_run_generations: simple_evolution needs alias_state");
     }
+    // sharded run (one process per GPU): this rank rolls out its own rows, the fitness shards are all-gathered INSIDE the loop
+    // (both transports of ses_allgather_fitness are plain stream enqueues), the strategy's tail follows
+    const bool multi = st->world > 1;
+    if (multi) {
+        SES_REQUIRE(st->comm && st->fit_local, "ses_run_generations: a sharded run needs the transport handle and fit_local");
+        SES_REQUIRE(st->per_rank >= 1 && (int64_t)st->per_rank * st->world >= st->n && st->first_row >= 0 &&
+                        st->first_row % st->per_rank == 0 && st->first_row / st->per_rank < st->world,
+                    "ses_run_generations: bad shard layout (%d ranks x %d rows for %d)", st->world, st->per_rank, st->n);
+        const int64_t left = (int64_t)st->n - st->first_row;
+        SES_REQUIRE(st->n_local == (int32_t)(left <= 0 ? 0 : left < st->per_rank ? left : st->per_rank),
+                    "ses_run_generations: n_local %d is not this rank's share of %d rows", st->n_local, st->n);
+        SES_REQUIRE(st->comm->stream == h->stream, "ses_run_generations: the transport handle must share the stream");
+    }
     unsigned long long *const saved_stamp = h->stamp;
     const int n = st->n, ke = st->elite_num;
+    const int n_loc = multi ? st->n_local : n;                         // rows of theta / init on this rank
+    const int64_t first = multi ? st->first_row : 0;
+    const bool sharded_tail = multi && openai && ses_openai_sharded_ok(h, st->comm, n, st->per_rank, st->world) == 1;
     int rc = SES_OK;
     // The env resets depend on (env seed, generation key) only: those of all k generations are drawn up front in ONE launch
     // (keyed like ESLoop._init_states), into a buffer the handle owns -- a 4 us kernel per generation less on the
     // critical path (the Python loop hides it on a side stream).  Above 64 MB the chunk is drawn generation by generation
     // into the caller's st->init instead.
-    const size_t slice = (size_t)(st->shared_init ? 1 : n) * h->cfg.eval_ep_num * st->init_width;
+    const int init_rows = st->shared_init ? 1 : (n_loc > 0 ? n_loc : 1);
+    const size_t slice = (size_t)init_rows * h->cfg.eval_ep_num * st->init_width;
     const bool ahead = slice * (size_t)k * sizeof(float) <= (64u << 20);
     if (ahead) {
         if (h->gen_init_cap < slice * (size_t)k) {
@@ -49,8 +66,8 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
             SES_HIP_TRY(hipMalloc(&h->gen_init, slice * (size_t)k * sizeof(float)));
             h->gen_init_cap = slice * (size_t)k;
         }
-        rc = ses_init_states_uniform_gens(h, st->env_seed, st->pop_gen, k, 0, st->shared_init ? 1 : n, st->shared_init, st->init_width,
-                                      st->init_lo, st->init_hi, h->gen_init);
+        rc = ses_init_states_uniform_gens(h, st->env_seed, st->pop_gen, k, st->shared_init ? 0 : first, init_rows, st->shared_init,
+                                          st->init_width, st->init_lo, st->init_hi, h->gen_init);
     }
     for (int g = 0; g < k && rc == SES_OK; ++g) {
         const int cur = st->cur, nxt = cur ^ 1;
@@ -58,13 +75,21 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
         if (ahead) {
             init = h->gen_init + slice * (size_t)g;
         } else {
-            rc = ses_init_states_uniform(h, st->env_seed, st->pop_gen, 0, st->shared_init ? 1 : n, st->shared_init, st->init_width,
-                                         st->init_lo, st->init_hi, st->init);
+            rc = ses_init_states_uniform(h, st->env_seed, st->pop_gen, st->shared_init ? 0 : first, init_rows, st->shared_init,
+                                         st->init_width, st->init_lo, st->init_hi, st->init);
             if (rc != SES_OK) break;
         }
         h->stamp = stamps ? (unsigned long long *)(stamps + 2 * g) : nullptr;          // end of the rollout phase
-        rc = ses_rollout(h, st->theta[cur], init, st->shared_init ? 0 : 1, n, st->mode, st->fitness, nullptr, nullptr);
+        if (n_loc > 0)
+            rc = ses_rollout(h, st->theta[cur], init, st->shared_init ? 0 : 1, n_loc, st->mode, multi ? st->fit_local : st->fitness,
+                             nullptr, nullptr);
         if (rc != SES_OK) break;
+        if (multi) {
+            // loop.py:66-79, the gather half of Pool.map: fitness[r * per_rank + i] = rank r's fit_local[i] (a ragged last
+            // shard ends in the -inf the caller put there once)
+            rc = ses_allgather_fitness(st->comm, st->fit_local, st->per_rank, st->fitness);
+            if (rc != SES_OK) break;
+        }
         unsigned long long *const tail_stamp = stamps ? (unsigned long long *)(stamps + 2 * g + 1) : nullptr;
         if (openai) {
             // optimizers.py:43-47 via Adam.next_step_scale(); offspring_strategies.py _evaluate_fused
@@ -74,9 +99,15 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
             const double sigma = st->sigma;
             st->sigma = st->sigma * st->sigma_decay;
             h->stamp = tail_stamp;
-            rc = ses_openai_generation(h, st->fitness, n, st->seed, st->pop_gen, st->learning_rate, sigma, a, st->parents[cur],
-                                       st->adam_m[cur], st->adam_v[cur], st->parents[nxt], st->adam_m[nxt], st->adam_v[nxt],
-                                       (float)st->sigma, st->pop_gen + 1, 0, n, st->theta[nxt], best + g);
+            if (sharded_tail)
+                rc = ses_openai_generation_sharded(h, st->comm, st->fitness, n, st->seed, st->pop_gen, st->learning_rate, sigma, a,
+                                                   st->parents[cur], st->adam_m[cur], st->adam_v[cur], st->parents[nxt],
+                                                   st->adam_m[nxt], st->adam_v[nxt], (float)st->sigma, st->pop_gen + 1, first,
+                                                   n_loc, st->per_rank, st->world, st->theta[nxt], best + g);
+            else
+                rc = ses_openai_generation(h, st->fitness, n, st->seed, st->pop_gen, st->learning_rate, sigma, a, st->parents[cur],
+                                           st->adam_m[cur], st->adam_v[cur], st->parents[nxt], st->adam_m[nxt], st->adam_v[nxt],
+                                           (float)st->sigma, st->pop_gen + 1, n_loc > 0 ? first : 0, n_loc, st->theta[nxt], best + g);
             st->pop_sigma = st->sigma;
         } else {
             int32_t *rank = st->work_i32, *ids = rank + n, *pidx = ids + ke, *alias = pidx + ke;
@@ -101,9 +132,9 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
                 st->sigma = st->sigma * st->sigma_decay;
             }
             h->stamp = tail_stamp;
-            if (rc == SES_OK)
-                rc = ses_perturb(h, st->parents[nxt], st->parent_map, nullptr, (float)st->pop_sigma, st->seed, st->pop_gen + 1, 0, n,
-                                 st->theta[nxt]);
+            if (rc == SES_OK && n_loc > 0)
+                rc = ses_perturb(h, st->parents[nxt], st->parent_map + first, nullptr, (float)st->pop_sigma, st->seed, st->pop_gen + 1,
+                                 first, n_loc, st->theta[nxt]);
         }
         st->pop_gen += 1;
         st->cur = nxt;

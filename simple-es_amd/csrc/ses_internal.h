@@ -48,6 +48,7 @@ struct ses_handle {
     int tune_lander_per_wave;      // offspring per wave of the lockstep lander rollout: 0 = by population size, 1 / 2 / 4
     int tune_comm_p2p_timeout_ms;  // how long a peer-store exchange waits for a peer (0 = the default, 60 s)
     int tune_comm_p2p_keep_going;  // 1: exchanges continue after a time-out (the host polls ses_comm_p2p_status and recovers)
+    int tune_openai_sharded_tail;  // 0: ses_openai_sharded_ok says no (sharded runs use the replicated openai_es tail; A/B runs)
 };
 
 namespace ses {

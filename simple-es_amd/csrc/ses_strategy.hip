@@ -144,10 +144,14 @@ __device__ __forceinline__ unsigned long long rank_key(uint32_t u, uint32_t inde
     return ((unsigned long long)ordered << 32) | (unsigned long long)index;
 }
 
-__global__ __launch_bounds__(256) void k_rank_count_fitness(const float *__restrict__ fit, int n, int jt,
-                                                            int32_t *__restrict__ rank)
+__global__ __launch_bounds__(256) void k_rank_count_fitness(const float *__restrict__ fit, int n, int jt, int first,
+                                                            int n_own, int32_t *__restrict__ rank)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // rows [first, first + n_own) of the population are counted against all n competitors; rank[] is indexed from `first`
+    // (first = 0, n_own = n: the whole population, every rank of a multi-GPU job the same; a shard's own rows only:
+    // ses_openai_generation_sharded)
+    const int il = blockIdx.x * 256 + threadIdx.x;
+    const int i = first + il;
     const int j0 = blockIdx.y * jt;
     const int lim = n - j0 < jt ? n - j0 : jt;
     const int ic = i < n ? i : n - 1;
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256) void k_rank_count_fitness(const float *__restr
         for (int e = 0; e < 16; ++e) count += (rank_key(c[e], (uint32_t)(j0 + k + e)) > ki) ? 1 : 0;
     }
     for (; k < lim; ++k) count += (rank_key(fj[k], (uint32_t)(j0 + k)) > ki) ? 1 : 0;
-    if (i < n && count) atomicAdd(&rank[i], count);
+    if (il < n_own && count) atomicAdd(&rank[il], count);
 }
 
 // Large populations (n > RANK_SORT_MIN): sort tiles of RANK_TILE keys in LDS (bitonic network), then every
@@ -173,32 +177,66 @@ __global__ __launch_bounds__(256) void k_rank_count_fitness(const float *__restr
 constexpr int RANK_TILE = 1024;
 constexpr int RANK_SORT_MIN = 8192;
 
-__global__ __launch_bounds__(RANK_TILE / 2) void k_rank_tile_sort(const unsigned long long *__restrict__ keys, int n,
-                                                                  unsigned long long *__restrict__ sorted)
+// Bitonic sort of one tile of RANK_TILE = 1024 keys by 512 threads, two keys per thread, ascending.  Wave w owns the
+// elements [128 w, 128 w + 128): lane l holds a = 128 w + l and b = a + 64, so every compare-exchange distance j <= 64 stays
+// inside the wave -- j = 64 between the thread's own two keys, j < 64 through a lane exchange (ds_bpermute) -- and only
+// the six stages with j >= 128 go through LDS, double-buffered so that each costs ONE barrier.  (First form: one
+// compare-exchange per thread per stage in LDS, 55 stages x (two reads, two writes, a barrier): 9 us per launch.)
+__device__ __forceinline__ void bitonic_keep(unsigned long long &x, unsigned long long y, bool keep_min)
 {
-    __shared__ unsigned long long t[RANK_TILE];
-    const int base = blockIdx.x * RANK_TILE;
-    for (int e = threadIdx.x; e < RANK_TILE; e += RANK_TILE / 2) t[e] = base + e < n ? keys[base + e] : 0ull;
-    __syncthreads();
+    const bool x_gt = x > y;
+    x = (x_gt == keep_min) ? y : x;
+}
+
+__device__ __forceinline__ void bitonic_sort_tile(unsigned long long &xa, unsigned long long &xb,
+                                                  unsigned long long (*buf)[RANK_TILE])
+{
+    const int a = (threadIdx.x >> 6) * 128 + (threadIdx.x & 63), b = a + 64;
+    int flip = 0;
+#pragma unroll
     for (int k = 2; k <= RANK_TILE; k <<= 1) {
+        const bool up_a = (a & k) == 0, up_b = (b & k) == 0;
+#pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            {
-                const int p = threadIdx.x;                                // one compare-exchange per thread
-                const int lo = ((p & ~(j - 1)) << 1) | (p & (j - 1));   // insert a 0 bit at position log2(j)
-                const int hi = lo | j;
-                const bool up = (lo & k) == 0;
-                const unsigned long long a = t[lo], b = t[hi];
-                if ((a > b) == up) { t[lo] = b; t[hi] = a; }
+            if (j >= 128) {
+                buf[flip][a] = xa;
+                buf[flip][b] = xb;
+                __syncthreads();
+                const unsigned long long ya = buf[flip][a ^ j], yb = buf[flip][b ^ j];
+                flip ^= 1;
+                bitonic_keep(xa, ya, ((a & j) == 0) == up_a);
+                bitonic_keep(xb, yb, ((b & j) == 0) == up_b);
+            } else if (j == 64) {
+                // a < b = a | 64: ascending (up) keeps the smaller key in a
+                const unsigned long long lo = xa < xb ? xa : xb, hi = xa < xb ? xb : xa;
+                xa = up_a ? lo : hi;
+                xb = up_a ? hi : lo;
+            } else {
+                const unsigned long long ya = __shfl_xor(xa, j, 64), yb = __shfl_xor(xb, j, 64);
+                bitonic_keep(xa, ya, ((a & j) == 0) == up_a);
+                bitonic_keep(xb, yb, ((b & j) == 0) == up_b);
             }
-            __syncthreads();
         }
     }
-    for (int e = threadIdx.x; e < RANK_TILE; e += RANK_TILE / 2) sorted[base + e] = t[e];   // ascending
+}
+
+// keys formed from the fitness values on the fly (no key array, no key kernel); padding keys are 0 and never count as larger
+__global__ __launch_bounds__(RANK_TILE / 2) void k_rank_tile_sort(const float *__restrict__ fit, int n,
+                                                                  unsigned long long *__restrict__ sorted)
+{
+    __shared__ unsigned long long buf[2][RANK_TILE];
+    const int base = blockIdx.x * RANK_TILE;
+    const int a = (threadIdx.x >> 6) * 128 + (threadIdx.x & 63), b = a + 64;
+    unsigned long long xa = base + a < n ? rank_key(f2u(fit[base + a]), (uint32_t)(base + a)) : 0ull;
+    unsigned long long xb = base + b < n ? rank_key(f2u(fit[base + b]), (uint32_t)(base + b)) : 0ull;
+    bitonic_sort_tile(xa, xb, buf);
+    sorted[base + a] = xa;                                                          // ascending
+    sorted[base + b] = xb;
 }
 
 // One workgroup = 256 offspring x one sorted tile: the tile (8 KB) is staged in LDS once and each thread binary-
 // searches it there (10 dependent LDS reads instead of 10 dependent L2 reads: 36 -> see DESIGN.md at 32 768).
-__global__ __launch_bounds__(256) void k_rank_search(const unsigned long long *__restrict__ keys,
+__global__ __launch_bounds__(256) void k_rank_search(const float *__restrict__ fit,
                                                      const unsigned long long *__restrict__ sorted, int n,
                                                      int32_t *__restrict__ rank)
 {
@@ -208,13 +246,46 @@ __global__ __launch_bounds__(256) void k_rank_search(const unsigned long long *_
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const unsigned long long ki = keys[i];
+    const unsigned long long ki = rank_key(f2u(fit[i]), (uint32_t)i);
     int lo = 0, hi = RANK_TILE;                      // first position with t[pos] > ki
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (t[mid] > ki) hi = mid; else lo = mid + 1;
     }
     if (lo < RANK_TILE) atomicAdd(&rank[i], RANK_TILE - lo);
+}
+
+// A shard's own rows against ALL tiles in one launch (ses_openai_generation_sharded): workgroup (x, y) sorts tile y
+// itself -- the sort is repeated by the n_own / 1024 workgroups that share the tile, a few microseconds of otherwise idle
+// CUs instead of a dependent launch -- and then searches it for its 1024 own rows, two per thread.
+__global__ __launch_bounds__(RANK_TILE / 2) void k_rank_sort_search(const float *__restrict__ fit, int n, int first,
+                                                                    int n_own, int32_t *__restrict__ rank_own)
+{
+    __shared__ unsigned long long buf[2][RANK_TILE];
+    const int base = blockIdx.y * RANK_TILE;
+    const int a = (threadIdx.x >> 6) * 128 + (threadIdx.x & 63), b = a + 64;
+    unsigned long long xa = base + a < n ? rank_key(f2u(fit[base + a]), (uint32_t)(base + a)) : 0ull;
+    unsigned long long xb = base + b < n ? rank_key(f2u(fit[base + b]), (uint32_t)(base + b)) : 0ull;
+    bitonic_sort_tile(xa, xb, buf);
+    // the sort's sixth and last LDS stage used buf[1]; every thread has passed its barrier, so the fifth stage's reads of
+    // buf[0] are over and buf[0] can take the sorted tile without another barrier
+    buf[0][a] = xa;
+    buf[0][b] = xb;
+    __syncthreads();
+    const unsigned long long *t = buf[0];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int il = blockIdx.x * RANK_TILE + half * (RANK_TILE / 2) + threadIdx.x;
+        if (il >= n_own) continue;
+        const int i = first + il;
+        const unsigned long long ki = rank_key(f2u(fit[i]), (uint32_t)i);
+        int lo = 0, hi = RANK_TILE;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (t[mid] > ki) hi = mid; else lo = mid + 1;
+        }
+        if (lo < RANK_TILE) atomicAdd(&rank_own[il], RANK_TILE - lo);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_rank_weights(const int32_t *__restrict__ rank, int n,
@@ -296,13 +367,25 @@ __global__ __launch_bounds__(256) void k_es_grad_partial(const double *__restric
 __global__ __launch_bounds__(256) void k_es_apply(const float *__restrict__ partial, int chunks, int P, int P4,
                                                   float update_factor, double adam_a, const float *mu, const float *m,
                                                   const float *v, float *mu_out, float *m_out, float *v_out,
-                                                  float *__restrict__ grad_out)
+                                                  float *__restrict__ grad_out, int cl, int stride, int n_cand,
+                                                  float *__restrict__ best)
 {
+    // chunk c's partial sits at partial[(c / cl) * stride + (c % cl) * P4 + p]: the all-gathered payloads of the ranks
+    // (cl chunks each, `stride` floats apart: ses_openai_generation_sharded) -- or one contiguous [chunks, P4] array
+    // (cl = chunks).  n_cand > 0: behind each rank's cl * P4 partials lie cl best-reward candidates as bit patterns
+    // (0xFFFFFFFF = none); the one that is there is max(fitness).
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p >= P) return;                                                  // wave-uniform
+    if (n_cand > 0 && p == 0) {
+        for (int c = lane; c < n_cand; c += 64) {
+            const uint32_t u = reinterpret_cast<const uint32_t *>(partial)[(size_t)(c / cl) * stride + (size_t)cl * P4 + c % cl];
+            if (u != 0xFFFFFFFFu && best) *best = __builtin_bit_cast(float, u);
+        }
+    }
     float sum = 0.0f;
     for (int base = 0; base < chunks; base += 64) {
-        const float mine = base + lane < chunks ? partial[(size_t)(base + lane) * P4 + p] : 0.0f;
+        const int cm = base + lane;
+        const float mine = cm < chunks ? partial[(size_t)(cm / cl) * stride + (size_t)(cm % cl) * P4 + p] : 0.0f;
         const int cnt = chunks - base < 64 ? chunks - base : 64;
         for (int c = 0; c < cnt; ++c) {
             const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), c));
@@ -343,19 +426,33 @@ __global__ __launch_bounds__(256) void k_es_grad_partial_ranked(const int32_t *_
                                                                 unsigned int *counter, int chunks, int P,
                                                                 float update_factor, double adam_a, const float *mu_in,
                                                                 const float *m_in, const float *v_in, float *mu_out,
-                                                                float *m_out, float *v_out)
+                                                                float *m_out, float *v_out, int first, int row_end,
+                                                                uint32_t *__restrict__ cand_out)
 {
+    // Shard form (ses_openai_generation_sharded): blockIdx.y counts the chunks of THIS rank's rows [first, row_end) --
+    // first is a multiple of ES_CHUNK, so they are chunks of the global population --, rank[] is indexed from `first`, and
+    // the chunk that holds the row of rank 0 reports its fitness as a bit pattern in cand_out[chunk] (0xFFFFFFFF = "not
+    // here"): the rows of the other ranks are not seen, the candidates travel with the partials.  Replicated form: first =
+    // 0, row_end = n, cand_out = null.
     __shared__ float red[4][256];
     __shared__ unsigned int ticket;
+    __shared__ uint32_t cand;
     const int q = blockIdx.x;
-    const int row0 = blockIdx.y * ES_CHUNK;
-    const int row1 = row0 + ES_CHUNK < n ? row0 + ES_CHUNK : n;
+    const int row0 = first + blockIdx.y * ES_CHUNK;
+    const int row1 = row0 + ES_CHUNK < row_end ? row0 + ES_CHUNK : row_end;
     const double nm1 = (double)(n - 1);
     const double sd = sqrt((double)(n + 1) / (12.0 * nm1));           // closed-form std of the rank grid
+    if (cand_out && q == 0) {                                          // uniform per workgroup
+        if (threadIdx.x == 0) cand = 0xFFFFFFFFu;
+        __syncthreads();
+    }
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int i = row0 + threadIdx.x; i < row1; i += 256) {
-        const int r = rank[i];
-        if (best && q == 0 && r == 0) *best = fitness[i];              // max(rewards), loop.py:82-84 `best_reward`
+        const int r = rank[i - first];
+        if (q == 0 && r == 0) {                                        // max(rewards), loop.py:82-84 `best_reward`
+            if (best) *best = fitness[i];
+            if (cand_out) cand = f2u(fitness[i]);
+        }
         if (skip_row0 && i == 0) continue;
         const double centred = ((double)(n - 1 - r) / nm1) - 0.5;      // offspring_strategies.py:394-396
         const float w = (float)(centred / sd);
@@ -375,6 +472,7 @@ __global__ __launch_bounds__(256) void k_es_grad_partial_ranked(const int32_t *_
         __syncthreads();
     }
     if (threadIdx.x < 4) partial[(size_t)blockIdx.y * P4 + 4 * q + threadIdx.x] = red[threadIdx.x][0];
+    if (cand_out && q == 0 && threadIdx.x == 0) cand_out[blockIdx.y] = cand;
     if (!FINAL) return;
     // ---- last workgroup of this quad done: finish the update of its 4 parameters ----
     if (threadIdx.x < 4) __threadfence();                              // this workgroup's partials are visible device-wide
@@ -591,13 +689,15 @@ int ses_rank_center(ses_handle *h, const float *fitness, int32_t n, int32_t *ran
     if (rc != SES_OK) return rc;
     h->rank_zeroed = nullptr;                       // this call lays the scratch out differently from ses_openai_generation
     h->counter_armed = nullptr;
-    unsigned long long *keys = (unsigned long long *)h->red_scratch;
-    hipLaunchKernelGGL(k_rank_keys, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, fitness, n, keys, rank);
     if (n > RANK_SORT_MIN) {
+        // sort + search, both with the keys formed from the fitness values on the fly
         unsigned long long *sorted = (unsigned long long *)((char *)h->red_scratch + key_bytes);
-        hipLaunchKernelGGL(k_rank_tile_sort, dim3(tiles), dim3(RANK_TILE / 2), 0, h->stream, keys, n, sorted);
-        hipLaunchKernelGGL(k_rank_search, dim3(ceil_div(n, 256), tiles), dim3(256), 0, h->stream, keys, sorted, n, rank);
+        SES_HIP_TRY(hipMemsetAsync(rank, 0, sizeof(int32_t) * (size_t)n, h->stream));
+        hipLaunchKernelGGL(k_rank_tile_sort, dim3(tiles), dim3(RANK_TILE / 2), 0, h->stream, fitness, n, sorted);
+        hipLaunchKernelGGL(k_rank_search, dim3(ceil_div(n, 256), tiles), dim3(256), 0, h->stream, fitness, sorted, n, rank);
     } else {
+        unsigned long long *keys = (unsigned long long *)h->red_scratch;
+        hipLaunchKernelGGL(k_rank_keys, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, fitness, n, keys, rank);
         hipLaunchKernelGGL(k_rank_count, dim3(ceil_div(n, 256), ceil_div(n, jt)), dim3(256), 0, h->stream, keys, n,
                            (int)jt, rank);
     }
@@ -630,7 +730,109 @@ int ses_es_update_philox(ses_handle *h, const double *weights, int32_t n, int32_
     hipLaunchKernelGGL(k_es_grad_partial, dim3(quads, chunks), dim3(256), 0, h->stream, weights, n, skip_row0, seed, gen,
                        P4, partial);
     hipLaunchKernelGGL(k_es_apply, dim3(ceil_div(h->P, 4)), dim3(256), 0, h->stream, partial, chunks, h->P, P4,
-                       (float)uf, adam_a, mu, m, v, mu, m, v, grad_out);
+                       (float)uf, adam_a, mu, m, v, mu, m, v, grad_out, chunks, 0, 0, (float *)nullptr);
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+// The openai_es tail.  comm == null: replicated (every rank ranks all n rows and regenerates all n x P normals).
+// comm != null: the shard form -- this rank ranks and accumulates only its own rows [first_row, first_row + n_rows), whose
+// per_rank-row slot is a whole number of the gradient's 1024-row chunks; the ranks all-gather their chunk partials (+ the
+// best-reward candidates) over `comm`, and the unchanged ordered update adds the chunks in ascending order: bit-identical
+// to the replicated form for any world size.
+static int openai_generation_impl(ses_handle *h, ses_handle *comm, const float *fitness, int32_t n, uint64_t seed, uint64_t gen,
+                                  double lr, double sigma, double adam_a, const float *mu_in, const float *m_in,
+                                  const float *v_in, float *mu_out, float *m_out, float *v_out, float next_sigma,
+                                  uint64_t next_gen, int64_t first_row, int32_t n_rows, int32_t per_rank, int32_t world,
+                                  float *theta_next, float *best)
+{
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    long long jt = ((long long)n * n / (256ll * 2048ll) + 63) / 64 * 64;
+    if (jt < 64) jt = 64;
+    if (jt > 8192) jt = 8192;
+    const int tiles = ceil_div(n, RANK_TILE);
+    const int quads = (h->P + 3) / 4, P4 = 4 * quads;
+    const int chunks = ceil_div(n, ES_CHUNK);
+    const bool sharded = comm != nullptr;
+    const bool count_rank = n <= RANK_SORT_MIN;                        // counting rank, keys formed inside the count
+    const int n_own = sharded ? n_rows : n;                            // rows this rank ranks and accumulates
+    const int first = sharded ? (int)first_row : 0;
+    const int cl = sharded ? per_rank / ES_CHUNK : chunks;             // chunks per rank's payload
+    const int stride = sharded ? (cl * P4 + cl + 3) / 4 * 4 : 0;       // floats per payload: cl x P4 partials, cl candidates
+    // scratch: sorted tiles (replicated sort path) | ranks of the own rows | local partials / payload | gathered payloads |
+    // ticket counters
+    const size_t sorted_bytes = (!sharded && !count_rank) ? sizeof(unsigned long long) * (size_t)tiles * RANK_TILE : 0;
+    const size_t rank_bytes = (sizeof(int32_t) * (size_t)(sharded ? per_rank : n) + 255) / 256 * 256;
+    const size_t local_bytes = (sizeof(float) * (size_t)(sharded ? stride : chunks * P4) + 255) / 256 * 256;
+    const size_t gathered_bytes = sharded ? (sizeof(float) * (size_t)stride * world + 255) / 256 * 256 : 0;
+    const int rc = ensure_reduce_scratch(h, sorted_bytes + rank_bytes + local_bytes + gathered_bytes + sizeof(unsigned int) * (size_t)quads);
+    if (rc != SES_OK) return rc;
+    unsigned long long *sorted = (unsigned long long *)h->red_scratch;
+    int32_t *rank = (int32_t *)((char *)h->red_scratch + sorted_bytes);
+    float *partial = (float *)((char *)rank + rank_bytes);
+    float *gathered = (float *)((char *)partial + local_bytes);
+    unsigned int *counter = (unsigned int *)((char *)gathered + gathered_bytes);
+    // The rank vector is zero on entry: cleared by the perturbation kernel at the end of the previous call, by a memset the
+    // first time (or whenever the scratch moved, or the layout / population size changed).
+    if (n_own > 0 && (h->rank_zeroed != rank || h->rank_zeroed_n != n_own)) {
+        SES_HIP_TRY(hipMemsetAsync(rank, 0, sizeof(int32_t) * (size_t)n_own, h->stream));
+        h->rank_zeroed = rank;
+        h->rank_zeroed_n = n_own;
+    }
+    if (n_own > 0) {
+        if (count_rank) {
+            hipLaunchKernelGGL(k_rank_count_fitness, dim3(ceil_div(n_own, 256), ceil_div(n, jt)), dim3(256), 0, h->stream, fitness,
+                               n, (int)jt, first, n_own, rank);
+        } else if (sharded) {
+            hipLaunchKernelGGL(k_rank_sort_search, dim3(ceil_div(n_own, RANK_TILE), tiles), dim3(RANK_TILE / 2), 0, h->stream,
+                               fitness, n, first, n_own, rank);
+        } else {
+            hipLaunchKernelGGL(k_rank_tile_sort, dim3(tiles), dim3(RANK_TILE / 2), 0, h->stream, fitness, n, sorted);
+            hipLaunchKernelGGL(k_rank_search, dim3(ceil_div(n, 256), tiles), dim3(256), 0, h->stream, fitness, sorted, n, rank);
+        }
+    }
+    double uf = lr / ((double)n * sigma);            // offspring_strategies.py:406-408
+    uf *= -1.0;
+    const bool final_in_grad = !sharded && chunks <= h->tune_es_final_max_chunks;   // Adam by the gradient kernel's finishing workgroups
+    if (final_in_grad) {
+        // the gradient kernel's finishing workgroups apply the update; the next launch perturbs the new mu
+        if (h->counter_armed != counter) {
+            SES_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int) * (size_t)quads, h->stream));
+            h->counter_armed = counter;
+        }
+        hipLaunchKernelGGL((k_es_grad_partial_ranked<true>), dim3(quads, chunks), dim3(256), 0, h->stream, rank, fitness, n, 1,
+                           seed, gen, P4, partial, best, counter, chunks, h->P, (float)uf, adam_a, mu_in, m_in, v_in, mu_out,
+                           m_out, v_out, 0, n, (uint32_t *)nullptr);
+    } else {
+        // a separate small launch finishes the update; this layout's partial[] may lie over the ticket counter of a
+        // smaller population's layout, so a cached "counter is zero" no longer holds
+        h->counter_armed = nullptr;
+        if (sharded) {
+            // every chunk of the slot is written, also the ones past the end of a ragged last shard (zeros, no candidate)
+            hipLaunchKernelGGL((k_es_grad_partial_ranked<false>), dim3(quads, cl), dim3(256), 0, h->stream, rank, fitness, n, 1,
+                               seed, gen, P4, partial, (float *)nullptr, counter, chunks, h->P, (float)uf, adam_a, mu_in, m_in,
+                               v_in, mu_out, m_out, v_out, first, first + n_own, (uint32_t *)(partial + (size_t)cl * P4));
+            SES_HIP_TRY(hipGetLastError());
+            const int arc = ses_allgather_fitness(comm, partial, stride, gathered);
+            if (arc != SES_OK) return arc;
+            hipLaunchKernelGGL(k_es_apply, dim3(ceil_div(h->P, 4)), dim3(256), 0, h->stream, gathered, chunks, h->P, P4,
+                               (float)uf, adam_a, mu_in, m_in, v_in, mu_out, m_out, v_out, (float *)nullptr, cl, stride,
+                               world * cl, best);
+        } else {
+            hipLaunchKernelGGL((k_es_grad_partial_ranked<false>), dim3(quads, chunks), dim3(256), 0, h->stream, rank, fitness, n, 1,
+                               seed, gen, P4, partial, best, counter, chunks, h->P, (float)uf, adam_a, mu_in, m_in, v_in, mu_out,
+                               m_out, v_out, 0, n, (uint32_t *)nullptr);
+            hipLaunchKernelGGL(k_es_apply, dim3(ceil_div(h->P, 4)), dim3(256), 0, h->stream, partial, chunks, h->P, P4,
+                               (float)uf, adam_a, mu_in, m_in, v_in, mu_out, m_out, v_out, (float *)nullptr, chunks, 0, 0,
+                               (float *)nullptr);
+        }
+    }
+    // the next population from the new mu; the launch also clears the rank vector for the next generation
+    {
+        const long long threads = (long long)(n_rows > 0 ? n_rows : 1) * quads;
+        hipLaunchKernelGGL(k_perturb_openai, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, mu_out, next_sigma, seed,
+                           next_gen, (long long)first_row, n_rows, h->P, quads, theta_next, h->stamp, rank, n_own);
+    }
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;
 }
@@ -645,79 +847,51 @@ int ses_openai_generation(ses_handle *h, const float *fitness, int32_t n, uint64
     SES_REQUIRE(n >= 2 && sigma != 0.0, "ses_openai_generation: bad n / sigma");
     SES_REQUIRE(n_rows >= 0 && first_row >= 0 && first_row + n_rows <= (int64_t)n && (n_rows == 0 || theta_next),
                 "ses_openai_generation: shard rows [%lld, +%d) outside the population of %d", (long long)first_row, n_rows, n);
-    SES_HIP_TRY(hipSetDevice(h->cfg.device));
-    // scratch: rank keys | sorted tiles or nothing | ranks | gradient partials
-    long long jt = ((long long)n * n / (256ll * 2048ll) + 63) / 64 * 64;
-    if (jt < 64) jt = 64;
-    if (jt > 8192) jt = 8192;
-    const int tiles = ceil_div(n, RANK_TILE);
-    const int quads = (h->P + 3) / 4, P4 = 4 * quads;
-    const int chunks = ceil_div(n, ES_CHUNK);
-    const size_t key_bytes = (sizeof(unsigned long long) * (size_t)n + 255) / 256 * 256;
-    const size_t sorted_bytes = sizeof(unsigned long long) * (size_t)tiles * RANK_TILE;
-    const size_t rank_bytes = (sizeof(int32_t) * (size_t)n + 255) / 256 * 256;
-    const int rc = ensure_reduce_scratch(h, key_bytes + sorted_bytes + rank_bytes + sizeof(float) * (size_t)chunks * P4 +
-                                                sizeof(unsigned int) * (size_t)quads);
-    if (rc != SES_OK) return rc;
-    unsigned long long *keys = (unsigned long long *)h->red_scratch;
-    unsigned long long *sorted = (unsigned long long *)((char *)h->red_scratch + key_bytes);
-    int32_t *rank = (int32_t *)((char *)h->red_scratch + key_bytes + sorted_bytes);
-    float *partial = (float *)((char *)h->red_scratch + key_bytes + sorted_bytes + rank_bytes);
-    // Small populations whose update runs in the fused kernel: keys formed inside the count (one launch less); the rank
-    // vector is zero on entry -- cleared by that fused kernel at the end of the previous call, by a memset the first time
-    // (or whenever the scratch moved or the population size changed).
-    const bool fused_count = n <= RANK_SORT_MIN;                       // keys formed inside the counting rank
-    const bool final_in_grad = chunks <= h->tune_es_final_max_chunks;  // Adam by the gradient kernel's finishing workgroups
-    if (fused_count) {
-        if (h->rank_zeroed != rank || h->rank_zeroed_n != n) {
-            SES_HIP_TRY(hipMemsetAsync(rank, 0, sizeof(int32_t) * (size_t)n, h->stream));
-            h->rank_zeroed = rank;
-            h->rank_zeroed_n = n;
-        }
-        hipLaunchKernelGGL(k_rank_count_fitness, dim3(ceil_div(n, 256), ceil_div(n, jt)), dim3(256), 0, h->stream, fitness,
-                           n, (int)jt, rank);
-    } else {
-        h->rank_zeroed = nullptr;
-        hipLaunchKernelGGL(k_rank_keys, dim3(ceil_div(n, 256)), dim3(256), 0, h->stream, fitness, n, keys, rank);
-        if (n > RANK_SORT_MIN) {
-            hipLaunchKernelGGL(k_rank_tile_sort, dim3(tiles), dim3(RANK_TILE / 2), 0, h->stream, keys, n, sorted);
-            hipLaunchKernelGGL(k_rank_search, dim3(ceil_div(n, 256), tiles), dim3(256), 0, h->stream, keys, sorted, n, rank);
-        } else {
-            hipLaunchKernelGGL(k_rank_count, dim3(ceil_div(n, 256), ceil_div(n, jt)), dim3(256), 0, h->stream, keys, n,
-                               (int)jt, rank);
-        }
-    }
-    double uf = lr / ((double)n * sigma);            // offspring_strategies.py:406-408
-    uf *= -1.0;
-    unsigned int *counter = (unsigned int *)((char *)partial + sizeof(float) * (size_t)chunks * P4);
-    if (final_in_grad) {
-        // the gradient kernel's finishing workgroups apply the update; the next launch perturbs the new mu
-        if (h->counter_armed != counter) {
-            SES_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned int) * (size_t)quads, h->stream));
-            h->counter_armed = counter;
-        }
-        hipLaunchKernelGGL((k_es_grad_partial_ranked<true>), dim3(quads, chunks), dim3(256), 0, h->stream, rank, fitness, n, 1,
-                           seed, gen, P4, partial, best, counter, chunks, h->P, (float)uf, adam_a, mu_in, m_in, v_in, mu_out,
-                           m_out, v_out);
-    } else {
-        // a separate small launch finishes the update; this layout's partial[] may lie over the ticket counter of a
-        // smaller population's layout, so a cached "counter is zero" no longer holds
-        h->counter_armed = nullptr;
-        hipLaunchKernelGGL((k_es_grad_partial_ranked<false>), dim3(quads, chunks), dim3(256), 0, h->stream, rank, fitness, n, 1,
-                           seed, gen, P4, partial, best, counter, chunks, h->P, (float)uf, adam_a, mu_in, m_in, v_in, mu_out,
-                           m_out, v_out);
-        hipLaunchKernelGGL(k_es_apply, dim3(ceil_div(h->P, 4)), dim3(256), 0, h->stream, partial, chunks, h->P, P4,
-                           (float)uf, adam_a, mu_in, m_in, v_in, mu_out, m_out, v_out, (float *)nullptr);
-    }
-    // the next population from the new mu; with the counting rank it also clears the rank vector for the next generation
-    if (n_rows > 0 || fused_count) {
-        const long long threads = (long long)(n_rows > 0 ? n_rows : 1) * quads;
-        hipLaunchKernelGGL(k_perturb_openai, dim3(ceil_div(threads, 256)), dim3(256), 0, h->stream, mu_out, next_sigma, seed,
-                           next_gen, (long long)first_row, n_rows, h->P, quads, theta_next, h->stamp,
-                           fused_count ? rank : (int32_t *)nullptr, fused_count ? n : 0);
-    }
-    SES_HIP_TRY(hipGetLastError());
-    return SES_OK;
+    return openai_generation_impl(h, nullptr, fitness, n, seed, gen, lr, sigma, adam_a, mu_in, m_in, v_in, mu_out, m_out, v_out,
+                                  next_sigma, next_gen, first_row, n_rows, 0, 1, theta_next, best);
+}
+
+// what the all-gather on `comm` can carry: (world of the transport that takes `floats` per rank) or 0
+static int comm_world_for(ses_handle *comm, int floats)
+{
+    int32_t pw = 0, cap = 0, rw = 0;
+    if (ses_comm_p2p_info(comm, &pw, &cap, nullptr) != SES_OK || ses_comm_info(comm, nullptr, &rw, nullptr) != SES_OK) return 0;
+    if (pw > 0 && floats <= cap && !(comm->tune_comm_force_rccl && rw > 0)) return pw;
+    return rw;
+}
+
+int ses_openai_sharded_ok(ses_handle *h, ses_handle *comm, int32_t n, int32_t per_rank, int32_t world)
+{
+    SES_REQUIRE(h && comm, "ses_openai_sharded_ok: null handle");
+    if (!h->tune_openai_sharded_tail || n < 2 || world < 2 || per_rank < ES_CHUNK || per_rank % ES_CHUNK != 0) return 0;
+    if ((long long)per_rank * (world - 1) >= n || (long long)per_rank * world < n) return 0;   // per_rank = ceil(n / world): every rank owns rows
+    if (comm->stream != h->stream || comm->cfg.device != h->cfg.device) return 0;
+    const int quads = (h->P + 3) / 4, cl = per_rank / ES_CHUNK;
+    const int stride = (cl * 4 * quads + cl + 3) / 4 * 4;
+    return comm_world_for(comm, stride) == world ? 1 : 0;
+}
+
+int ses_openai_generation_sharded(ses_handle *h, ses_handle *comm, const float *fitness, int32_t n, uint64_t seed, uint64_t gen,
+                                  double lr, double sigma, double adam_a, const float *mu_in, const float *m_in,
+                                  const float *v_in, float *mu_out, float *m_out, float *v_out, float next_sigma,
+                                  uint64_t next_gen, int64_t first_row, int32_t n_rows, int32_t per_rank, int32_t world,
+                                  float *theta_next, float *best)
+{
+    SES_REQUIRE(h && comm && fitness && mu_in && m_in && v_in && mu_out && m_out && v_out, "ses_openai_generation_sharded: null argument");
+    SES_REQUIRE(mu_in != mu_out && m_in != m_out && v_in != v_out, "ses_openai_generation_sharded: in and out vectors must be distinct buffers");
+    SES_REQUIRE(n >= 2 && sigma != 0.0, "ses_openai_generation_sharded: bad n / sigma");
+    const int ok = ses_openai_sharded_ok(h, comm, n, per_rank, world);
+    if (ok < 0) return ok;
+    if (!ok)
+        return set_error(SES_ERR_UNSUPPORTED, "ses_openai_generation_sharded: %d rows as %d shards of %d are not chunk-aligned "
+                         "(%d rows), or `comm` has no transport of %d ranks for the payload on this stream: use "
+                         "ses_openai_generation (ses_openai_sharded_ok tells)", n, world, per_rank, ES_CHUNK, world);
+    SES_REQUIRE(first_row >= 0 && first_row % per_rank == 0 && first_row < (int64_t)n &&
+                    n_rows == (int32_t)((int64_t)n - first_row < per_rank ? (int64_t)n - first_row : per_rank) && theta_next,
+                "ses_openai_generation_sharded: rows [%lld, +%d) are not a rank's shard of %d x %d", (long long)first_row, n_rows,
+                world, per_rank);
+    return openai_generation_impl(h, comm, fitness, n, seed, gen, lr, sigma, adam_a, mu_in, m_in, v_in, mu_out, m_out, v_out,
+                                  next_sigma, next_gen, first_row, n_rows, per_rank, world, theta_next, best);
 }
 
 int ses_es_update_stored(ses_handle *h, const double *weights, int32_t n, const float *eps_store, double lr,

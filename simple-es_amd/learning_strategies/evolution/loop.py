@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 from ses import HipES, MODE_EPISODIC, MODE_FIXED_LENGTH
-from ses.parallel import attach_comm, comm_failed, comm_recover
+from ses.parallel import attach_comm, comm_failed, comm_keep_going, comm_recover
 
 from .abstracts import BaseESLoop
 
@@ -35,10 +35,22 @@ class _GenerationBatch:
         from learning_strategies.evolution.offspring_strategies import openai_es, simple_evolution, simple_genetic
         hooked = any(name in loop.__dict__ or getattr(type(loop), name) is not getattr(ESLoop, name)
                      for name in ("rollout", "generation", "_init_states"))        # a caller observing the per-generation methods
-        return (population.shard.world == 1 and type(strategy) in (openai_es, simple_evolution, simple_genetic)
+        shard = population.shard
+        dist_world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if shard.world != dist_world:
+            return False
+        if shard.world > 1:
+            # sharded run: the C loop all-gathers the fitness itself, so a LIBRARY transport (peer stores or RCCL) has to
+            # carry the shards; with torch.distributed as the only route the per-generation path stays
+            owner = getattr(loop.dev, "_comm_owner", None)
+            if owner is None:
+                return False
+            p2p_world, cap, rccl_world = owner.comm_route()
+            if not ((p2p_world == shard.world and shard.per_rank <= cap) or rccl_world == shard.world):
+                return False
+        return (type(strategy) in (openai_es, simple_evolution, simple_genetic)
                 and strategy.noise == "philox" and getattr(strategy, "fused", True) and hasattr(loop.dev, "run_generations")
-                and not hooked and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-                and os.environ.get("SES_BATCH_GENERATIONS", "1") != "0")
+                and not hooked and os.environ.get("SES_BATCH_GENERATIONS", "1") != "0")
 
     def __init__(self, loop, strategy, population):
         import numpy as np
@@ -46,7 +58,9 @@ class _GenerationBatch:
         from ses import _lib
         dev, P = loop.dev, strategy.P
         self.loop, self.strategy, self.dev = loop, strategy, dev
-        n = population.theta.shape[0]
+        shard = population.shard
+        n = shard.n_global                  # population rows; this rank's theta holds shard.n_local of them
+        n_loc = shard.n_local
         st = _lib.SesGenState()
         self.kind = (_lib.STRATEGY_OPENAI_ES if isinstance(strategy, openai_es) else
                      _lib.STRATEGY_SIMPLE_EVOLUTION if isinstance(strategy, simple_evolution) else _lib.STRATEGY_SIMPLE_GENETIC)
@@ -60,7 +74,7 @@ class _GenerationBatch:
         st.sigma, st.pop_sigma = strategy.curr_sigma, strategy._last["sigma"]
         st.pop_gen = population.gen
         keep = self.keep = {}
-        keep["theta"] = [population.theta.contiguous(), dev.empty(n, P)]
+        keep["theta"] = [population.theta.contiguous() if n_loc else dev.empty(1, P), dev.empty(max(n_loc, 1), P)]
         if self.kind == _lib.STRATEGY_OPENAI_ES:
             opt = strategy.optimizer
             st.adam_t = opt.t
@@ -88,16 +102,23 @@ class _GenerationBatch:
             st.parent_map, st.work_i32, st.work_f32 = keep["map"].data_ptr(), keep["wi"].data_ptr(), keep["wf"].data_ptr()
             if "alias" in keep:
                 st.alias_state = keep["alias"].data_ptr()
-        keep["fitness"] = dev.empty(n)
-        keep["init"] = dev.empty(1 if loop.shared_init else n, dev.E, dev.init_dim)
+        keep["fitness"] = dev.empty(shard.per_rank * shard.world if shard.world > 1 else n)
+        keep["init"] = dev.empty(1 if loop.shared_init else max(n_loc, 1), dev.E, dev.init_dim)
         st.fitness, st.init = keep["fitness"].data_ptr(), keep["init"].data_ptr()
+        if shard.world > 1:
+            # this rank's slot of the all-gather: the rollout writes the first n_local entries, a ragged tail stays -inf
+            keep["fit_local"] = torch.full((shard.per_rank,), float("-inf"), dtype=torch.float32, device=dev.device)
+            keep["comm"] = dev._comm_owner
+            st.world, st.per_rank, st.n_local = shard.world, shard.per_rank, n_loc
+            st.first_row = shard.rank * shard.per_rank
+            st.comm, st.fit_local = keep["comm"]._h.value, keep["fit_local"].data_ptr()
         for i in (0, 1):
             st.theta[i], st.parents[i] = keep["theta"][i].data_ptr(), keep["parents"][i].data_ptr()
             if "m" in keep:
                 st.adam_m[i], st.adam_v[i] = keep["m"][i].data_ptr(), keep["v"][i].data_ptr()
         st.cur = 0
         self.st = st
-        self.shard = population.shard
+        self.shard = shard
         # two chunks in flight: pinned rings the kernels store the best reward / the time stamps into
         self.best = [torch.full((self.K_MAX,), float("nan"), dtype=torch.float32).pin_memory() for _ in range(2)]
         self.stamps = [torch.zeros(self.K_MAX, 2, dtype=torch.int64).pin_memory() for _ in range(2)]
@@ -135,7 +156,7 @@ class _GenerationBatch:
             s.elite_models = parents
         s._last = {"parents": parents.view(-1, s.P), "idx_host": self.map_host, "sigma": st.pop_sigma, "gen": int(st.pop_gen),
                    "shard": self.shard}
-        return Population(keep["theta"][cur], self.shard, s.network, s.agent_ids, int(st.pop_gen))
+        return Population(keep["theta"][cur][: self.shard.n_local], self.shard, s.network, s.agent_ids, int(st.pop_gen))
 
 
 class ESLoop(BaseESLoop):
@@ -194,6 +215,7 @@ class ESLoop(BaseESLoop):
         self._prev_tail = 0
         self._tail_stamped = False
         self._guarded = False
+        self.batched_generations = 0       # generations of run() that went through ses_run_generations (tests read it)
 
     def _init_states(self, gen, shard):
         """The env resets of generation `gen` for this rank's rows.  They depend on (env seed, generation, row) only, so they
@@ -321,76 +343,102 @@ class ESLoop(BaseESLoop):
                   f"({self.env_variant}; parity with gym / Box2D is unpinned, see README)")
         guarded = offsprings.shard.world > 1 and hasattr(strategy, "snapshot") and getattr(strategy, "noise", "") == "philox"
         self._guarded = guarded
-        if _GenerationBatch.eligible(self, strategy, offsprings):
-            return self._run_batched(strategy, offsprings, rank0)
+        # a guarded run owns a recovery (below): only then may a timed-out exchange be followed by further ones
+        comm_keep_going(self.dev, guarded)
+        try:
+            return self._run_segments(strategy, offsprings, rank0, guarded)
+        finally:
+            comm_keep_going(self.dev, False)
+
+    def _run_segments(self, strategy, offsprings, rank0, guarded):
+        """The run as segments between boundaries -- checkpoint generations, the end, and for a guarded (multi-GPU) run at
+        least every comm_check_period generations.  Inside a segment the generations go to the device k at a time through
+        ses_run_generations (one C call instead of ~10 Python-level calls per generation; on several GPUs too: the fitness
+        all-gather is issued by the C loop) when _GenerationBatch.eligible says so, one ESLoop.generation() at a time
+        otherwise; both forms are bit-identical (tests/test_gpu_host_mirror.py, tests/test_gpu_multirank.py).  At a boundary
+        every generation has been reported; a guarded run then agrees across the ranks whether an exchange timed out since
+        the last boundary and, if so, rolls back to it."""
+        period = self.save_model_period
         snap = (0, strategy.snapshot(offsprings), len(self.history), list(self.ep5_rewards)) if guarded else None
-        pending = None
+        batch = _GenerationBatch(self, strategy, offsprings) if _GenerationBatch.eligible(self, strategy, offsprings) else None
         self._last_report = 0.0
         ep_num = 0
         while ep_num < self.generation_num:
-            ep_num += 1
-            start_time = time.time()
-            offsprings, best, curr_sigma, events = self.generation(offsprings)
-            if pending is not None:
-                self._report(*pending, rank0)
-            pending = (ep_num, best, curr_sigma, events, start_time, self._tail_stamped)
-            checkpoint = ep_num % self.save_model_period == 0
-            if checkpoint or (guarded and (ep_num - snap[0] >= self.comm_check_period or ep_num == self.generation_num)):
-                self._report(*pending, rank0)      # a boundary generation is reported before anything is written
+            boundary = min(self.generation_num, (ep_num // period + 1) * period)
+            if guarded:
+                boundary = min(boundary, snap[0] + self.comm_check_period)
+            if batch is not None:
                 pending = None
-                if guarded:
-                    if comm_recover(self.dev):     # collective: some rank's exchange timed out since the last boundary
-                        ep_num = snap[0]
-                        offsprings = strategy.restore(snap[1])
-                        del self.history[snap[2]:]
-                        self.ep5_rewards.clear()
-                        self.ep5_rewards.extend(snap[3])
-                        self._prev_tail = 0
-                        continue
-                    snap = (ep_num, strategy.snapshot(offsprings), len(self.history), list(self.ep5_rewards))
-                if checkpoint and rank0:
-                    elite = strategy.get_elite_model()
-                    torch.save(elite.state_dict(), self.save_dir + "/saved_models" + f"/ep_{ep_num}.pt")
-                    self._metrics.flush()
-        if pending is not None:
-            self._report(*pending, rank0)
+                while ep_num < boundary:
+                    k = min(batch.K_MAX, boundary - ep_num)
+                    t0 = time.time()
+                    best, stamps, sigmas = batch.run(k)
+                    self.batched_generations += k
+                    if pending is not None:
+                        self._report_chunk(pending, rank0)
+                    pending = (ep_num + 1, k, best, stamps, sigmas, t0)
+                    ep_num += k
+                self._report_chunk(pending, rank0)     # a boundary generation is reported before anything is written
+                offsprings = batch.sync_back()
+            else:
+                pending = None
+                while ep_num < boundary:
+                    ep_num += 1
+                    start_time = time.time()
+                    offsprings, best, curr_sigma, events = self.generation(offsprings)
+                    if pending is not None:
+                        self._report(*pending, rank0)
+                    pending = (ep_num, best, curr_sigma, events, start_time, self._tail_stamped)
+                self._report(*pending, rank0)
+            if guarded:
+                if comm_recover(self.dev):     # collective: some rank's exchange timed out since the last boundary
+                    ep_num = snap[0]
+                    offsprings = strategy.restore(snap[1])
+                    del self.history[snap[2]:]
+                    self.ep5_rewards.clear()
+                    self.ep5_rewards.extend(snap[3])
+                    self._prev_tail = 0
+                    if rank0 and self._metrics is not None:      # the rows of the replayed generations above this one are void
+                        self._metrics.write(json.dumps({"rollback_to": ep_num}) + "\n")
+                    # the transport has changed: the device-side loop continues only if a library transport is left
+                    batch = (_GenerationBatch(self, strategy, offsprings)
+                             if _GenerationBatch.eligible(self, strategy, offsprings) else None)
+                    continue
+                snap = (ep_num, strategy.snapshot(offsprings), len(self.history), list(self.ep5_rewards))
+            if ep_num % period == 0 and rank0:
+                elite = strategy.get_elite_model()
+                torch.save(elite.state_dict(), self.save_dir + "/saved_models" + f"/ep_{ep_num}.pt")
+                self._metrics.flush()
         return offsprings
 
-
-    def _run_batched(self, strategy, offsprings, rank0):
-        """run() on one GPU: the generations go to the device k at a time through ses_run_generations (one C call instead
-        of ~10 Python-level calls per generation), two chunks in flight; prints, metrics and checkpoints as in _run().
-        Bit-identical to the per-generation path (tests/test_gpu_host_mirror.py)."""
+    def _report_chunk(self, chunk, rank0):
         from learning_strategies.evolution.offspring_strategies import PendingReward
-        batch = _GenerationBatch(self, strategy, offsprings)
-        self._last_report = 0.0
-        ep_num, pending = 0, None
+        first, k, best, stamps, sigmas, t0 = chunk
+        for j in range(k):
+            self._report(first + j, PendingReward(best[j:j + 1]), sigmas[j], stamps[j], t0, True, rank0)
 
-        def report(chunk):
-            first, k, best, stamps, sigmas, t0 = chunk
-            for j in range(k):
-                self._report(first + j, PendingReward(best[j:j + 1]), sigmas[j], stamps[j], t0, True, rank0)
-
-        while ep_num < self.generation_num:
-            to_boundary = self.save_model_period - ep_num % self.save_model_period
-            k = min(batch.K_MAX, self.generation_num - ep_num, to_boundary)
-            t0 = time.time()
-            best, stamps, sigmas = batch.run(k)
-            if pending is not None:
-                report(pending)
-            pending = (ep_num + 1, k, best, stamps, sigmas, t0)
-            ep_num += k
-            if ep_num % self.save_model_period == 0:
-                report(pending)
-                pending = None
-                batch.sync_back()
-                if rank0:
-                    elite = strategy.get_elite_model()
-                    torch.save(elite.state_dict(), self.save_dir + "/saved_models" + f"/ep_{ep_num}.pt")
-                    self._metrics.flush()
-        if pending is not None:
-            report(pending)
-        return batch.sync_back()
+    def generations(self, offsprings, k):
+        """Enqueue k generations without waiting for the GPU and without the per-generation bookkeeping of run(): through
+        ses_run_generations when the run is eligible for it (bench.py's timed call on several GPUs), k x generation()
+        otherwise.  Returns the next offspring group."""
+        strategy = self.offspring_strategy
+        batch = getattr(self, "_bench_batch", None)
+        if batch is None or batch[0] is not offsprings:
+            batch = None
+            if _GenerationBatch.eligible(self, strategy, offsprings):
+                batch = (offsprings, _GenerationBatch(self, strategy, offsprings))
+        if batch is None:
+            for _ in range(k):
+                offsprings, _best, _sigma, _stamp = self.generation(offsprings)
+            return offsprings
+        done = 0
+        while done < k:
+            step = min(batch[1].K_MAX, k - done)
+            batch[1].run(step)
+            done += step
+        pop = batch[1].sync_back()
+        self._bench_batch = (pop, batch[1])
+        return pop
 
 
 class _Ready:

@@ -24,7 +24,7 @@ import torch
 
 from learning_strategies.optimizers import Adam
 from ses import HipES
-from ses.parallel import Shard
+from ses.parallel import Shard, attach_comm
 
 from .abstracts import BaseOffspringStrategy
 from .utils import wrap_agentid
@@ -126,7 +126,8 @@ class _DeviceStrategy(BaseOffspringStrategy):
         self.network = network
         network.zero_init()           # every strategy starts from the zero network (offspring_strategies.py:83,200,348)
         self.dev = HipES(None, network.num_state, network.num_action, network.discrete_action, network.use_gru)
-        self.P = self.dev.P
+        attach_comm(self.dev)         # multi-GPU: the shard form of the openai_es tail exchanges its chunk partials (collective
+        self.P = self.dev.P           # only the first time a process attaches; ESLoop has done that)
         self._ring = _ReadbackRing(self.dev.device)
         self._shards = {}
 
@@ -437,9 +438,10 @@ class openai_es(_DeviceStrategy):
         self.curr_sigma *= self.sigma_decay
         n = self.offspring_num
         shard = self._shard(n)
+        comm = self._sharded_tail_comm(n, shard)
         theta = self.dev.openai_generation(fit, self.seed, self._last["gen"], self.learning_rate, sigma, a, state_in,
                                            state_out, self.curr_sigma, self.gen, shard.first, shard.n_local,
-                                           best=self._ring.arm())
+                                           best=self._ring.arm(), comm=comm, per_rank=shard.per_rank, world=shard.world)
         best = self._ring.push()
         self._spare = state_in
         self.mu_model, opt.m, opt.v = state_out
@@ -449,6 +451,19 @@ class openai_es(_DeviceStrategy):
         pop = Population(theta, shard, self.network, self.agent_ids, self.gen)
         self.gen += 1
         return pop, best, self.curr_sigma
+
+    def _sharded_tail_comm(self, n, shard):
+        """The transport handle for ses_openai_generation_sharded, or None for the replicated tail: the shard form needs
+        shards aligned to the gradient's 1024-row chunks and a library transport for the chunk partials (asked once per
+        layout and transport state; the tuning knob "openai_sharded_tail" = 0 forces the replicated form, for A/B runs)."""
+        owner = getattr(self.dev, "_comm_owner", None)
+        if shard.world == 1 or owner is None:
+            return None
+        key = (n, shard.per_rank, shard.world, owner.comm_route())
+        if getattr(self, "_sharded_key", None) != key:
+            self._sharded_key = key
+            self._sharded_ok = self.dev.openai_sharded_ok(owner, n, shard.per_rank, shard.world)
+        return owner if self._sharded_ok else None
 
     def _snapshot_state(self):
         opt = self.optimizer

@@ -47,12 +47,14 @@ class SesGenState(ctypes.Structure):
         ("learning_rate", ctypes.c_double), ("sigma_decay", ctypes.c_double),
         ("sigma", ctypes.c_double), ("pop_sigma", ctypes.c_double),
         ("pop_gen", ctypes.c_uint64), ("adam_t", ctypes.c_int64),
-        ("cur", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("cur", ctypes.c_int32), ("world", ctypes.c_int32),
         ("theta", ctypes.c_void_p * 2), ("parents", ctypes.c_void_p * 2),
         ("adam_m", ctypes.c_void_p * 2), ("adam_v", ctypes.c_void_p * 2),
         ("parent_map", ctypes.c_void_p), ("alias_state", ctypes.c_void_p),
         ("fitness", ctypes.c_void_p), ("init", ctypes.c_void_p),
         ("work_i32", ctypes.c_void_p), ("work_f32", ctypes.c_void_p),
+        ("first_row", ctypes.c_int64), ("n_local", ctypes.c_int32), ("per_rank", ctypes.c_int32),
+        ("comm", ctypes.c_void_p), ("fit_local", ctypes.c_void_p),
     ]
 
 
@@ -93,6 +95,9 @@ SIGNATURES = {
     "ses_es_update_philox": [_vp, _vp, _i32, _i32, _u64, _u64, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
     "ses_openai_generation": [_vp, _vp, _i32, _u64, _u64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _u64, _i64, _i32,
                               _vp, _vp],
+    "ses_openai_sharded_ok": [_vp, _vp, _i32, _i32, _i32],
+    "ses_openai_generation_sharded": [_vp, _vp, _vp, _i32, _u64, _u64, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _u64,
+                                      _i64, _i32, _i32, _i32, _vp, _vp],
     "ses_es_update_stored": [_vp, _vp, _i32, _vp, _f64, _f64, _f64, _vp, _vp, _vp, _vp],
     "ses_elite_ids": [_vp, _vp, _i32, _i32, _vp],
     "ses_elite_select": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
@@ -106,6 +111,7 @@ SIGNATURES = {
     "ses_allgather_fitness": [_vp, _vp, _i32, _vp],
     "ses_comm_p2p_export": [_vp, _i32, _i32, _i32, _vp],
     "ses_comm_p2p_attach": [_vp, _vp],
+    "ses_comm_p2p_attach_local": [_vp, _vp],
     "ses_comm_p2p_info": [_vp, _vp, _vp, _vp],
     "ses_comm_p2p_status": [_vp, _vp],
     "ses_comm_p2p_detach": [_vp],

@@ -210,6 +210,13 @@ class HipES:
         check(self._lib.ses_comm_p2p_attach(self._h, ctypes.create_string_buffer(blob, len(blob))), "ses_comm_p2p_attach")
         self._route = None
 
+    def comm_p2p_attach_local(self, peers):
+        """ses_comm_p2p_attach_local: `peers` = the HipES handles of all ranks of this process, in rank order (each has
+        exported its mailbox and has a stream of its own)."""
+        arr = (ctypes.c_void_p * len(peers))(*[p._h.value for p in peers])
+        check(self._lib.ses_comm_p2p_attach_local(self._h, arr), "ses_comm_p2p_attach_local")
+        self._route = None
+
     def comm_p2p_info(self):
         """(world, max_per_rank, exchanges); world == 0 means the peer-store transport is not attached."""
         w, m, x = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
@@ -434,10 +441,19 @@ class HipES:
                                              _ptr(grad)), "ses_es_update_philox")
         return grad
 
+    def openai_sharded_ok(self, comm, n, per_rank, world):
+        """ses_openai_sharded_ok: can the openai_es tail of this layout run in its shard form over `comm`'s transport?"""
+        rc = self._lib.ses_openai_sharded_ok(self._h, comm._h, int(n), int(per_rank), int(world))
+        if rc < 0:
+            check(rc, "ses_openai_sharded_ok")
+        return rc == 1
+
     def openai_generation(self, fitness, seed, gen, lr, sigma, adam_a, state_in, state_out, next_sigma, next_gen,
-                          first_row, n_rows, theta_next=None, best=None):
-        """ses_openai_generation: rank shaping + ES gradient + Adam + the next population in four launches (six above 8192 rows).
-        state_in / state_out: (mu, m, v) triples of distinct float32[P] tensors.  Returns theta_next[n_rows, P]."""
+                          first_row, n_rows, theta_next=None, best=None, comm=None, per_rank=0, world=1):
+        """ses_openai_generation: rank shaping + ES gradient + Adam + the next population in four launches (five above 8192 rows).
+        state_in / state_out: (mu, m, v) triples of distinct float32[P] tensors.  Returns theta_next[n_rows, P].
+        comm (a HipES that owns a transport of `world` ranks) selects ses_openai_generation_sharded: this rank ranks and
+        accumulates its own rows only, the chunk partials are all-gathered over comm (openai_sharded_ok says when)."""
         n = fitness.shape[0]
         self._chk(fitness, "fitness", torch.float32, (n,))
         for name, t in zip(("mu_in", "m_in", "v_in", "mu_out", "m_out", "v_out"), tuple(state_in) + tuple(state_out)):
@@ -449,6 +465,12 @@ class HipES:
             raise SesError(f"openai_generation: rows [{first_row}, +{n_rows}) outside the population of {n}")
         theta = (self.empty(n_rows, self.P) if theta_next is None else
                  self._chk(theta_next, "theta_next", torch.float32, (n_rows, self.P)))
+        if comm is not None:
+            check(self._lib.ses_openai_generation_sharded(
+                self._h, comm._h, _ptr(fitness), int(n), int(seed), int(gen), float(lr), float(sigma), float(adam_a),
+                *[_ptr(t) for t in state_in], *[_ptr(t) for t in state_out], float(next_sigma), int(next_gen), int(first_row),
+                int(n_rows), int(per_rank), int(world), _ptr(theta), _ptr(best)), "ses_openai_generation_sharded")
+            return theta
         check(self._lib.ses_openai_generation(self._h, _ptr(fitness), int(n), int(seed), int(gen), float(lr), float(sigma),
                                               float(adam_a), *[_ptr(t) for t in state_in], *[_ptr(t) for t in state_out],
                                               float(next_sigma), int(next_gen), int(first_row), int(n_rows),

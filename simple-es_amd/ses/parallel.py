@@ -63,9 +63,8 @@ def _attach_p2p(owner, rank, world, group):
     ok = _cpu_group_ok(ok, owner.device, group)            # also: nobody starts the test before everybody has attached
     if ok:
         try:
-            # a wait that times out marks the exchange and the run goes on; ESLoop.run() polls the status word, agrees with
-            # the other ranks at its checkpoint boundaries and rolls back onto the next transport (comm_recover below)
-            owner.set_tuning("comm_p2p_keep_going", 1)
+            # ("comm_p2p_keep_going" stays 0 here: the exchange AFTER a timed-out one fails loudly with SES_ERR_COMM.  Only a
+            # caller that owns a recovery -- ESLoop.run() for a guarded run, comm_keep_going below -- switches it on.)
             if os.environ.get("SES_COMM_P2P_TIMEOUT_MS"):
                 owner.set_tuning("comm_p2p_timeout_ms", int(os.environ["SES_COMM_P2P_TIMEOUT_MS"]))
             n = 257
@@ -137,6 +136,16 @@ def attach_comm(dev, group=None, allow_single=False):
         return False
     dev._comm_owner = owner
     return True
+
+
+def comm_keep_going(dev, on):
+    """Let `dev`'s peer-store exchanges continue after a time-out (NaN-filled shards, status word set) instead of failing the
+    next call.  ONLY for a caller that polls comm_failed / comm_recover and rolls back: ESLoop.run() switches it on for a
+    guarded run and off again when the run ends; everybody else (RolloutWorker, bench legs, strategies with
+    noise='numpy', user code calling attach_comm) keeps the loud failure."""
+    owner = getattr(dev, "_comm_owner", None)
+    if owner is not None and owner.comm_route()[0]:
+        owner.set_tuning("comm_p2p_keep_going", 1 if on else 0)
 
 
 def comm_failed(dev):

@@ -206,3 +206,223 @@ def test_a_frozen_rank_costs_a_rollback_not_the_run(tmp_path):
             else:
                 assert list(got["transports"]) == ["torch", "torch"]
         assert list(np.load(tmp_path / f"fz_{name}_w2_r0.npz")["saved"]) == ["ep_8.pt"]
+
+
+# ---- round 4: the shard form of the openai_es tail and the device-side generation loop on several ranks -----------------
+
+SHARDED_WORKER = textwrap.dedent("""
+    import contextlib, io, os, sys
+    import numpy as np, torch
+    sys.path[:0] = [%r, %r]
+    out_dir, world = sys.argv[1], int(os.environ.get("WORLD_SIZE", "1"))
+    sizes = [int(x) for x in sys.argv[2].split(",")]
+    batched = sys.argv[3] == "batched"
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    rank = int(os.environ.get("RANK", "0"))
+    import builder
+    os.chdir(out_dir)
+    for n in sizes:
+        cfg = {"env": {"name": "CartPole-v1", "max_step": 25, "pomdp": False, "seed": 3},
+               "network": {"name": "gym_model", "num_state": 4, "num_action": 2, "discrete_action": True, "gru": False},
+               "strategy": {"name": "openai_es", "init_sigma": 0.5, "sigma_decay": 0.99, "learning_rate": 0.05,
+                            "offspring_num": n, "seed": 5}}
+        loop = builder.build_loop(cfg, 5, 1, 2, False, 10 ** 9)
+        fits = []
+        if not batched:                      # observing the rollouts keeps run() on the per-generation path
+            orig = loop.rollout
+            loop.rollout = lambda pop, _o=orig: (fits.append(_o(pop).cpu().numpy().copy()) or torch.from_numpy(fits[-1]).cuda())
+        with contextlib.redirect_stdout(io.StringIO()):
+            pop = loop.run()
+        strat = loop.offspring_strategy
+        sharded = False
+        if world > 1:
+            owner = getattr(strat.dev, "_comm_owner", None)
+            sharded = owner is not None and strat.dev.openai_sharded_ok(owner, n, pop.shard.per_rank, world)
+        np.savez(os.path.join(out_dir, f"sh_{n}_w{world}_r{rank}.npz"), fits=np.stack(fits) if fits else np.zeros(0),
+                 elite=strat.get_elite_model().flat(), best=np.array([b for b, _ in loop.history]),
+                 m=strat.optimizer.m.cpu().numpy(), v=strat.optimizer.v.cpu().numpy(), theta=pop.theta.cpu().numpy(),
+                 first=pop.shard.first, sharded=sharded, batched_generations=loop.batched_generations)
+    if world > 1:
+        dist.destroy_process_group()
+""")
+
+
+def _run_ranks(script, tmp_path, world, extra, env=None, timeout=900):
+    cmd = ([sys.executable, str(script), str(tmp_path)] if world == 1 else
+           [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script), str(tmp_path)]) + list(extra)
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env={**os.environ, "SES_COMM_P2P": "1", **(env or {})})
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+    return run
+
+
+@pytest.mark.parametrize("world,sizes,mode", [(2, "2048,10239", "stepwise"), (4, "4096,12285", "stepwise"),
+                                              (2, "2048,10239", "batched"), (4, "12285", "batched")],
+                         ids=["2_ranks", "4_ranks", "2_ranks_device_loop", "4_ranks_device_loop"])
+def test_sharded_openai_tail_equals_one_rank_bitwise(tmp_path, world, sizes, mode):
+    """Shards aligned to the gradient's 1024-row chunks: every rank ranks and accumulates its own rows only, the chunk
+    partials (and the best-reward candidates) are all-gathered through the mailboxes, the ordered update finishes --
+    fitness vectors, best rewards, parent, Adam moments and the next population's rows equal the one-rank run bit for bit.
+    2048 rows: counting rank; 10 239 / 12 285: one sort + search launch, last shard ragged (5119 of 5120, 3069 of 3072
+    rows).  `device_loop`: the same through ESLoop.run()'s ses_run_generations path, all-gather inside the C loop."""
+    script = tmp_path / "sh.py"
+    script.write_text(SHARDED_WORKER % (ROOT, SRC))
+    _run_ranks(script, tmp_path, 1, [sizes, mode])
+    _run_ranks(script, tmp_path, world, [sizes, mode])
+    for n in (int(x) for x in sizes.split(",")):
+        ref = np.load(tmp_path / f"sh_{n}_w1_r0.npz")
+        assert len(ref["best"]) == 5 and np.isfinite(ref["best"]).all()
+        for r in range(world):
+            got = np.load(tmp_path / f"sh_{n}_w{world}_r{r}.npz")
+            assert bool(got["sharded"]), (n, r, "the shard form was not available")
+            for key in ("fits", "elite", "m", "v"):
+                assert np.array_equal(got[key].view(np.uint32), ref[key].view(np.uint32)), (n, r, key)
+            assert np.array_equal(got["best"], ref["best"]), (n, r)
+            lo = int(got["first"])
+            assert np.array_equal(got["theta"].view(np.uint32), ref["theta"][lo:lo + got["theta"].shape[0]].view(np.uint32)), (n, r)
+            assert int(got["batched_generations"]) == (5 if mode == "batched" else 0)
+        assert int(ref["batched_generations"]) == (5 if mode == "batched" else 0)
+
+
+BATCHED_WORKER = textwrap.dedent("""
+    import contextlib, io, os, sys, time
+    import numpy as np, torch
+    sys.path[:0] = [%r, %r]
+    out_dir, world = sys.argv[1], int(os.environ.get("WORLD_SIZE", "1"))
+    freeze = len(sys.argv) > 2 and sys.argv[2] == "freeze"
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    rank = int(os.environ.get("RANK", "0"))
+    import builder
+    from learning_strategies.evolution import loop as loop_mod
+    from ses.parallel import comm_transport
+    loop_mod.ESLoop.comm_check_period = 4
+    os.chdir(out_dir)
+    for name, n in (("openai_es", 203), ("simple_evolution", 96), ("simple_genetic", 120)):
+        cfg = {"env": {"name": "CartPole-v1", "max_step": 100, "pomdp": False, "seed": 3},
+               "network": {"name": "gym_model", "num_state": 4, "num_action": 2, "discrete_action": True, "gru": False},
+               "strategy": {"name": name, "init_sigma": 0.5, "sigma_decay": 0.99, "learning_rate": 0.05,
+                            "elite_num": 8, "offspring_num": n, "seed": 5}}
+        loop = builder.build_loop(cfg, 12, 1, 3, False, 8)
+        before = comm_transport(loop.dev) if world > 1 else "none"
+        calls = [0]
+        orig = loop_mod._GenerationBatch.run
+        def run(self, k, _o=orig):
+            calls[0] += 1
+            if freeze and world > 1 and rank == 1 and calls[0] == 2 and name == "openai_es":
+                torch.cuda.synchronize()
+                time.sleep(1.5)                      # this rank freezes for five time-outs of its peer
+            return _o(self, k)
+        loop_mod._GenerationBatch.run = run
+        with contextlib.redirect_stdout(io.StringIO()):
+            loop.run()
+        loop_mod._GenerationBatch.run = orig
+        after = comm_transport(loop.dev) if world > 1 else "none"
+        elite = loop.offspring_strategy.get_elite_model().flat()
+        saved = sorted(os.listdir(os.path.join(loop.save_dir, "saved_models"))) if loop.save_dir else []
+        rows = [l for l in open(os.path.join(loop.save_dir, "metrics.jsonl"))] if loop.save_dir else []
+        np.savez(os.path.join(out_dir, f"bt_{name}_w{world}_r{rank}.npz"), elite=elite, best=np.array([b for b, _ in loop.history]),
+                 sigma=np.array([s for _, s in loop.history]), transports=np.array([before, after]), calls=calls[0],
+                 saved=np.array(saved), batched_generations=loop.batched_generations,
+                 rollbacks=sum('"rollback_to"' in l for l in rows))
+    if world > 1:
+        dist.destroy_process_group()
+""")
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_device_side_loop_on_several_ranks_equals_one_rank(tmp_path, world):
+    """ESLoop.run() with no observer: on several ranks, too, the generations go to the device through ses_run_generations
+    (rollout of the own rows, fitness all-gather by peer stores INSIDE the C loop, the strategy's tail, the own rows of the
+    next population), all three strategies, shards of 203 / 97 / 120 rows that no chunk boundary divides (the replicated
+    tail) -- history, sigma trace, parent and the one checkpoint equal the one-rank run."""
+    script = tmp_path / "bt.py"
+    script.write_text(BATCHED_WORKER % (ROOT, SRC))
+    _run_ranks(script, tmp_path, 1, [])
+    _run_ranks(script, tmp_path, world, [])
+    for name in ("openai_es", "simple_evolution", "simple_genetic"):
+        ref = np.load(tmp_path / f"bt_{name}_w1_r0.npz")
+        assert int(ref["batched_generations"]) == 12
+        for r in range(world):
+            got = np.load(tmp_path / f"bt_{name}_w{world}_r{r}.npz")
+            assert list(got["transports"]) == ["p2p-store", "p2p-store"], got["transports"]
+            assert int(got["batched_generations"]) == 12, (name, r)
+            assert np.array_equal(got["elite"].view(np.uint32), ref["elite"].view(np.uint32)), (name, r)
+            assert np.array_equal(got["best"], ref["best"]) and np.array_equal(got["sigma"], ref["sigma"]), (name, r)
+        assert list(np.load(tmp_path / f"bt_{name}_w{world}_r0.npz")["saved"]) == ["ep_8.pt"]
+
+
+def test_a_frozen_rank_in_the_device_side_loop_costs_a_rollback(tmp_path):
+    """The same freeze as above, but inside the ses_run_generations path: rank 1 sleeps 1.5 s before it enqueues its second
+    chunk of generations, rank 0's exchanges give up after 0.3 s (then after 2 ms each: the peer is known to be late),
+    both meet at the boundary, drop the transport, roll back and replay on the per-generation path over torch.distributed
+    (this rig has no RCCL between processes of one GPU).  Results equal the undisturbed one-rank run; metrics.jsonl says
+    which rows were superseded."""
+    script = tmp_path / "bt.py"
+    script.write_text(BATCHED_WORKER % (ROOT, SRC))
+    _run_ranks(script, tmp_path, 1, [])
+    two = _run_ranks(script, tmp_path, 2, ["freeze"], env={"SES_COMM_P2P_TIMEOUT_MS": "300"})
+    assert "timed out" in two.stderr
+    for name in ("openai_es", "simple_evolution", "simple_genetic"):
+        ref = np.load(tmp_path / f"bt_{name}_w1_r0.npz")
+        for r in range(2):
+            got = np.load(tmp_path / f"bt_{name}_w2_r{r}.npz")
+            assert np.array_equal(got["elite"].view(np.uint32), ref["elite"].view(np.uint32)), (name, r)
+            assert np.array_equal(got["best"], ref["best"]) and np.array_equal(got["sigma"], ref["sigma"]), (name, r)
+            if name == "openai_es":
+                assert list(got["transports"]) == ["p2p-store", "torch"], got["transports"]
+                assert 0 < int(got["batched_generations"]) <= 12
+            else:
+                assert list(got["transports"]) == ["torch", "torch"] and int(got["batched_generations"]) == 0
+        r0 = np.load(tmp_path / f"bt_{name}_w2_r0.npz")
+        assert list(r0["saved"]) == ["ep_8.pt"]
+        assert int(r0["rollbacks"]) == (1 if name == "openai_es" else 0)
+
+
+UNGUARDED_WORKER = textwrap.dedent("""
+    import os, sys, time
+    import numpy as np, torch
+    sys.path[:0] = [%r, %r]
+    out_dir = sys.argv[1]
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    from ses import HipES
+    from ses._lib import SesError
+    from ses.parallel import Shard, attach_comm, comm_failed, comm_transport
+    dev = HipES("CartPole-v1", 4, 2, True, False)
+    assert attach_comm(dev) and comm_transport(dev, 512) == "p2p-store"
+    shard = Shard(1024)
+    local = torch.full((512,), float(rank + 1), device=dev.device)
+    outcome = "none"
+    if rank == 1:
+        torch.cuda.synchronize(); time.sleep(1.2)         # far beyond rank 0's time-out
+        got = shard.allgather_fitness(local, dev=dev); torch.cuda.synchronize()
+        outcome = "late rank: " + ("ok" if bool((got[:512] == 1).all()) else "bad")
+    else:
+        got = shard.allgather_fitness(local, dev=dev); torch.cuda.synchronize()
+        nan_shard = bool(torch.isnan(got[512:]).all()) and bool((got[:512] == 1).all())
+        try:
+            shard.allgather_fitness(local, dev=dev)
+            outcome = "second exchange went through"
+        except SesError as exc:
+            outcome = f"nan_shard={nan_shard} failed={comm_failed(dev)} raised: {exc}"
+    open(os.path.join(out_dir, f"ug_r{rank}.txt"), "w").write(outcome)
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_an_unguarded_caller_fails_loudly_after_a_timed_out_exchange(tmp_path):
+    """attach_comm leaves "comm_p2p_keep_going" off: whoever all-gathers without ESLoop's roll-back (RolloutWorker, bench
+    legs, noise='numpy' strategies, user code) consumes ONE NaN-marked shard and the next exchange raises SES_ERR_COMM --
+    a stalled peer cannot feed NaN fitness into ranking, updates and checkpoints indefinitely."""
+    script = tmp_path / "ug.py"
+    script.write_text(UNGUARDED_WORKER % (ROOT, SRC))
+    _run_ranks(script, tmp_path, 2, [], env={"SES_COMM_P2P_TIMEOUT_MS": "200"})
+    r0 = open(tmp_path / "ug_r0.txt").read()
+    assert r0.startswith("nan_shard=True failed=True raised:") and "timed out" in r0 and "code -5" in r0, r0
+    assert open(tmp_path / "ug_r1.txt").read() == "late rank: ok"
