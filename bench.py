@@ -165,16 +165,19 @@ def env_step_roofline(es, n_env, launches=20, batches=15, preroll=200):
     copy13 = BYTES_PER_ENV_STEP * n_env / probe_avg / 1e9
     # the same kernel and probe with as many waves in flight as the CUs take (256 threads, no LDS reserved: the shape of
     # rounds 1-3a): what limiting the waves in flight is worth on this box
-    es.set_tuning("env_step_block", 256)
-    es.set_tuning("env_step_lds_bytes", 0)
-    for _ in range(5):
-        step()
+    shape = es.env_step_shape()                           # (block, LDS bytes reserved, waves per CU) of the default: derived from the device
     wide_steps, wide_probes = [], []
-    for _ in range(3):                                   # (few launches: they share the kernel's name in a rocprofv3 trace)
-        wide_steps.append(batch(step, 10))
-        wide_probes.append(batch(probe, 10))
-    es.set_tuning("env_step_block", 64)
-    es.set_tuning("env_step_lds_bytes", 22528)
+    try:
+        es.set_tuning("env_step_block", 256)
+        es.set_tuning("env_step_lds_bytes", 0)
+        for _ in range(5):
+            step()
+        for _ in range(3):                               # (few launches: they share the kernel's name in a rocprofv3 trace)
+            wide_steps.append(batch(step, 10))
+            wide_probes.append(batch(probe, 10))
+    finally:                                             # whatever happens above, the later legs see the default shape again
+        es.set_tuning("env_step_block", shape[0])
+        es.set_tuning("env_step_lds_bytes", -1)
     # torch's device-to-device copy of the same byte count (read half, write half: two streams)
     half = BYTES_PER_ENV_STEP * n_env // 2
     src, dst = torch.empty(half, dtype=torch.uint8, device="cuda"), torch.empty(half, dtype=torch.uint8, device="cuda")
@@ -190,8 +193,10 @@ def env_step_roofline(es, n_env, launches=20, batches=15, preroll=200):
             "best_batch_us": min(steps) * 1e6,
             "copy13_us": probe_avg * 1e6, "copy13_gbs": copy13, "frac_of_copy13": achieved / copy13,
             "copy13": "ses_stream_probe: the same 7 load + 6 store streams, float4 non-temporal, no arithmetic, same launch shape",
-            "launch_shape": "single-wave workgroups, each reserving 22 KB of LDS it never touches: 7 waves per CU in flight "
-                            "(ses_env_step; tools/envstep_ab.hip has the sweep)",
+            "launch_shape": f"{shape[0]}-thread workgroups, each reserving {shape[1]} bytes of LDS it never touches (derived from the "
+                            f"device's LDS per CU): {shape[2]} waves per CU in flight by the occupancy calculator "
+                            "(ses_env_step_shape; tools/envstep_ab.hip has the sweep)",
+            "launch_block": shape[0], "launch_lds_bytes": shape[1], "waves_per_cu": shape[2],
             "unlimited_waves_us": statistics.median(wide_steps) * 1e6,
             "unlimited_waves_frac": BYTES_PER_ENV_STEP * n_env / statistics.median(wide_steps) / 1e9 / HBM_PEAK_GBS,
             "unlimited_waves_copy13_us": statistics.median(wide_probes) * 1e6,

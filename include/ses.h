@@ -92,8 +92,10 @@ int ses_sync(ses_handle *h);
  * "rollout_waves8" (1024: light waves of the mixed CartPole MLP split), "rollout_mix_light" (their lanes per env: 0 = choose | 8 | 16), "rollout_block" (64 | 256), "lander_offspring_per_wave" (0 = by population size | 1 | 2 | 4),
  * "box2d_lanes_per_env" (0 = by population size | 1 | 2 | ... | 64: lanes that share one env in the LunarLander / BipedalWalker MLP rollout),
  * "box2d_envs_per_wave" (0 = by population size | 1 ... 64 / lanes per env: different envs a wave of that rollout carries),
- * "env_step_block" (64 | 128 | 256) and "env_step_lds_bytes" (0 ... 65536): workgroup size of ses_env_step's kernel and the LDS
- * each workgroup reserves without touching it -- 64 and 22528 keep 7 waves per CU in flight, which is what the memory system wants,
+ * "env_step_block" (64 | 128 | 256), "env_step_waves_per_cu" (1 ... 32, default 7) and "env_step_lds_bytes" (-1 ... 65536,
+ * default -1): workgroup size of ses_env_step's kernel and the LDS each workgroup reserves without touching it -- -1 derives
+ * the reservation from the device's LDS per CU so that env_step_waves_per_cu waves stay in flight (7 is what the memory
+ * system wants; ses_env_step_shape reports what the occupancy calculator makes of it), >= 0 is taken as given,
  * "es_final_max_chunks" (0: ses_openai_generation applies Adam in its own small launch; k > 0: inside the gradient kernel for
  * populations of up to k * 1024 rows), "comm_force_rccl" (1: ses_allgather_fitness uses the RCCL communicator although the
  * peer-store transport is attached -- for measuring one against the other), "comm_p2p_timeout_ms" (how long a peer-store
@@ -190,6 +192,11 @@ int ses_env_obs_width(ses_handle *h);
 int ses_env_reset(ses_handle *h, const float *init, int32_t n, void *state, float *obs);
 int ses_env_step_generic(ses_handle *h, void *state, const void *action, int32_t n, float *obs, float *reward,
                          int32_t *done);
+
+/* The launch shape ses_env_step (and ses_stream_probe) use on this device with the current knobs: threads per workgroup, the
+ * LDS bytes each workgroup reserves, and the waves per CU the HIP occupancy calculator gives that shape (0: unknown).  Any
+ * pointer may be NULL. */
+int ses_env_step_shape(ses_handle *h, int32_t *block, int32_t *lds_bytes, int32_t *waves_per_cu);
 
 /* Measurement aid for the roofline of ses_env_step (no reference counterpart): the same 13 streams -- 7 x 16-byte
  * non-temporal loads and 6 x 16-byte non-temporal stores per lane over the same arrays, same grid -- with no arithmetic

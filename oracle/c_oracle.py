@@ -26,7 +26,9 @@ def build(force=False):
     src_m = max(os.path.getmtime(f) for f in srcs)
 
     def stale():
-        return not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m
+        # (both libraries of the Makefile's `all`: the oracle and its all-iterations checker build of the Box2D-style world)
+        return any(not os.path.exists(so) or os.path.getmtime(so) < src_m
+                   for so in (_SO, os.path.join(os.path.dirname(_SO), "libses_b2_allits.so")))
 
     if force or stale():
         # One builder at a time: the bench's CPU-baseline pool has a worker per host core, each of which gets here when the
@@ -243,6 +245,13 @@ def toi_probe(body, edge, start, end):
     e, a, b = _f32(edge), _f32(start), _f32(end)
     state = lib().o_toi_probe(int(body), _p(e), _p(a), _p(b), ctypes.byref(t))
     return int(state), float(t.value)
+
+
+def walker_body_props():
+    """[5, 5] float32: mass, inertia about the centre of mass, local centre x, y, mixed friction -- the float32 world's tables"""
+    props = np.empty((5, 5), dtype=np.float32)
+    lib().o_walker_body_props(_p(props))
+    return props
 
 
 class WalkerSim:

@@ -161,6 +161,17 @@ float o_walker_step(void *state, const float *action4, float *obs, int32_t *done
     return r;
 }
 
+// the float32 world's tables for the five walker bodies: props[5][5] = mass, inertia about the centre of mass, local centre x, y,
+// friction mixed with the terrain's (tests/test_oracle_walker.py compares them with what oracle/walker64.c derives from gym's polygons)
+void o_walker_body_props(float *props)
+{
+    for (int b = 0; b < 5; ++b) {
+        const BodyDef &d = WALKER_BODY[b];
+        const float v[5] = {1.0f / d.inv_mass, 1.0f / d.inv_i, d.lcx, d.lcy, d.friction};
+        memcpy(props + 5 * b, v, sizeof v);
+    }
+}
+
 // diagnostics for the tests: bodies [5][6] (c, a, v, w), terrain [200], flags {game_over, contact points, limit states x4,
 // touching manifolds of each leg body x4}
 void o_walker_debug(const void *state, float *bodies, float *terrain, int32_t *ints)

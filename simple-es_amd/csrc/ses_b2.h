@@ -28,8 +28,14 @@
 // per-contact TOI cache (every pair is re-evaluated after an event), a sub-step for a hull that touches (the touch ends
 // the episode; what the sub-step would do is never observed).
 //
-// All N velocity iterations are run, as in Box2D: with the light legs on the heavy hull the joint rows converge by
-// about 3 % per iteration (measured), a fixed point is not reached earlier.  Quantities that Box2D recomputes in every
+// The N velocity iterations of Box2D are all run -- or, what has the same result bit for bit, the loop is left once an
+// iteration has returned every velocity and every accumulated impulse with the bits it started from: the iteration is a
+// deterministic map of exactly those values, so all later iterations are identities.  Two places use that: the lander's main
+// loop compares once, after iteration D::VEL_FIXED_POINT_CHECK (ses_lander_env.h has the census; with the light legs on the
+// heavy hull the joint rows otherwise converge by about 3 % per iteration and no fixed point comes), and a time-of-impact
+// sub-step compares after every iteration (one body against one or two manifolds: ~25 iterations).  Both comparisons are
+// bitwise (-0 is not +0).  A build with -DB2_RUN_ALL_ITERATIONS takes neither exit; tests/test_oracle_lander.py holds the
+// two builds of the host oracle to identical trajectories.  Quantities that Box2D recomputes in every
 // iteration from values that do not change during a step (the inverse of the joint's 3x3 mass matrix) are computed once
 // per step and applied as a matrix-vector product: same algorithm, results differ from Box2D's at rounding level.
 #pragma once
@@ -1211,12 +1217,16 @@ B2_FN void world_solve_toi(World<D> &w, const T &terr, Sweep (&sw)[D::NB], float
                         }
                         B2_UNROLL
                         for (int s = 0; s < D::NSLOT; ++s) contact_solve_velocity(mt[s], ct[s], B, bd);
-                        bool same = vx0 == B.vx && vy0 == B.vy && w0 == B.w;
+                        uint32_t diff = (B2_F2U(vx0) ^ B2_F2U(B.vx)) | (B2_F2U(vy0) ^ B2_F2U(B.vy)) | (B2_F2U(w0) ^ B2_F2U(B.w));
                         B2_UNROLL
                         for (int s = 0; s < D::NSLOT; ++s)
-                            same = same && imp0[s][0] == mt[s].ni[0] && imp0[s][1] == mt[s].ni[1] && imp0[s][2] == mt[s].ti[0] &&
-                                   imp0[s][3] == mt[s].ti[1];
-                        if (same) break;
+                            diff |= (B2_F2U(imp0[s][0]) ^ B2_F2U(mt[s].ni[0])) | (B2_F2U(imp0[s][1]) ^ B2_F2U(mt[s].ni[1])) |
+                                    (B2_F2U(imp0[s][2]) ^ B2_F2U(mt[s].ti[0])) | (B2_F2U(imp0[s][3]) ^ B2_F2U(mt[s].ti[1]));
+#ifndef B2_RUN_ALL_ITERATIONS
+                        if (diff == 0u) break;                              // bitwise: -0 is not +0, as in the main loop
+#else
+                        (void)diff;
+#endif
                     }
                     const float h = (1.0f - min_alpha) * dt;
                     const float trx = h * B.vx, try_ = h * B.vy;

@@ -124,7 +124,14 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     h->tune_box2d_lpe = 0;
     h->tune_box2d_epw = 0;
     h->tune_env_step_block = 64;
-    h->tune_env_step_lds = 22528;
+    h->tune_env_step_lds = -1;                // derived from the device: lds_per_cu / tune_env_step_waves (ses_rollout.hip: env_step_shape)
+    h->tune_env_step_waves = 7;
+    h->env_step_key[0] = -2;
+    {
+        int lds = 0;
+        SES_HIP_TRY(hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, cfg->device));
+        h->lds_per_cu = lds;
+    }
     h->tune_openai_sharded_tail = 1;
     h->tune_es_final_max_chunks = 0;          // measured: the wave-per-parameter update launch beats the in-kernel finisher
     *out = h;
@@ -150,7 +157,8 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"box2d_lanes_per_env", &ses_handle::tune_box2d_lpe, 0, 64},
                                  {"box2d_envs_per_wave", &ses_handle::tune_box2d_epw, 0, 64},
                                  {"env_step_block", &ses_handle::tune_env_step_block, 64, 256},
-                                 {"env_step_lds_bytes", &ses_handle::tune_env_step_lds, 0, 65536},
+                                 {"env_step_lds_bytes", &ses_handle::tune_env_step_lds, -1, 65536},
+                                 {"env_step_waves_per_cu", &ses_handle::tune_env_step_waves, 1, 32},
                                  {"es_final_max_chunks", &ses_handle::tune_es_final_max_chunks, 0, 1 << 20},
                                  {"comm_force_rccl", &ses_handle::tune_comm_force_rccl, 0, 1},
                                  {"comm_p2p_timeout_ms", &ses_handle::tune_comm_p2p_timeout_ms, 0, 1 << 30},

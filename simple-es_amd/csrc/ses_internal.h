@@ -43,7 +43,13 @@ struct ses_handle {
     int tune_es_final_max_chunks;  // ses_openai_generation: up to this many 1024-row chunks the gradient kernel applies Adam itself
     int tune_box2d_lpe;            // lanes per env of the Box2D MLP rollout: 0 = by population size, 1 / 2 / 4 / ... / 64
     int tune_env_step_block;       // threads per workgroup of the standalone env-step kernel (64)
-    int tune_env_step_lds;         // bytes of LDS each of its workgroups reserves without touching them: limits the waves in flight (22528)
+    int tune_env_step_lds;         // bytes of LDS each of its workgroups reserves without touching them: limits the waves in flight;
+                                   // -1 (default): derived from the device's LDS per CU and tune_env_step_waves
+    int tune_env_step_waves;       // waves per CU the derived reservation keeps in flight (7: what the memory system wants)
+    int lds_per_cu;                // hipDeviceAttributeMaxSharedMemoryPerMultiprocessor of the handle's device
+    int env_step_key[3];           // (block, lds knob, waves knob) the two values below were resolved for
+    int env_step_lds_resolved;     // the reservation actually launched with
+    int env_step_wpc;              // waves per CU the occupancy calculator gives that shape
     int tune_box2d_epw;            // different envs per wave of the Box2D MLP rollout: 0 = by population size, else <= 64 / lanes per env
     int tune_lander_per_wave;      // offspring per wave of the lockstep lander rollout: 0 = by population size, 1 / 2 / 4
     int tune_comm_p2p_timeout_ms;  // how long a peer-store exchange waits for a peer (0 = the default, 60 s)

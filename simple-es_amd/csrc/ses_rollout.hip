@@ -1254,11 +1254,48 @@ static void launch_cartpole_mlp(const ses_handle *h, const float *theta, const f
 struct EnvStepShape {
     int blocks, block, lds;
 };
-static EnvStepShape env_step_shape(const ses_handle *h, int n4)
+// The LDS reservation that limits the waves in flight.  Knob "env_step_lds_bytes" >= 0: taken as given.  -1 (default):
+// derived from the device -- its LDS per CU divided by the workgroups per CU that make "env_step_waves_per_cu" (7) waves,
+// rounded down to 256 bytes and checked against the occupancy calculator (the allocation granule is the hardware's
+// business: if the rounded figure still lets one more workgroup in, or one fewer, it is moved by 256 bytes until the
+// calculator agrees).  Resolved once per (block, knobs); env_step_wpc is what the calculator says in the end.
+static void env_step_resolve(ses_handle *h)
+{
+    const int block = h->tune_env_step_block;
+    if (h->env_step_key[0] == block && h->env_step_key[1] == h->tune_env_step_lds && h->env_step_key[2] == h->tune_env_step_waves) return;
+    auto occupancy = [&](int lds) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_env_step_cartpole_v4<true>, block, (size_t)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            nb = 0;
+        }
+        return nb;
+    };
+    int lds = h->tune_env_step_lds;
+    if (lds < 0) {
+        int wgs = h->tune_env_step_waves * 64 / block;                     // workgroups per CU that make the wanted waves
+        if (wgs < 1) wgs = 1;
+        lds = h->lds_per_cu > 0 ? h->lds_per_cu / wgs / 256 * 256 : 0;
+        if (lds > 65536) lds = 65536;                                       // what one workgroup may ask for
+        for (int tries = 0; tries < 16 && lds > 256; ++tries) {
+            const int nb = occupancy(lds);
+            if (nb == 0 || nb == wgs) break;                                // (0: no calculator -- keep the arithmetic figure)
+            if (nb < wgs) lds -= 256;                                       // a granule rounded it up past the share
+            else if (lds + 256 <= 65536 && occupancy(lds + 256) >= wgs) lds += 256;
+            else break;
+        }
+    }
+    h->env_step_lds_resolved = lds;
+    h->env_step_wpc = occupancy(lds) * block / 64;
+    h->env_step_key[0] = block; h->env_step_key[1] = h->tune_env_step_lds; h->env_step_key[2] = h->tune_env_step_waves;
+}
+
+static EnvStepShape env_step_shape(ses_handle *h, int n4)
 {
     EnvStepShape sh;
+    env_step_resolve(h);
     sh.block = h->tune_env_step_block;
-    sh.lds = h->tune_env_step_lds;
+    sh.lds = h->env_step_lds_resolved;
     const long long want = ceil_div((long long)n4, sh.block);
     sh.blocks = want < (1 << 20) ? (int)want : (1 << 20);                   // beyond that the kernel strides
     return sh;
@@ -1422,11 +1459,13 @@ int ses_env_step(ses_handle *h, int32_t n, int32_t mode, float *x, float *xd, fl
     const int max_step = h->cfg.max_step;
     if (n4 > 0) {
         // One float4 group per thread, a one-shot grid -- and FEW WAVES IN FLIGHT: single-wave workgroups that each reserve
-        // 22 KB of LDS they never touch, so that a CU holds 7 of them instead of 32 waves.  Thirteen streams from 8192
+        // a seventh of the CU's LDS (22.5 KB of 160 on gfx950; derived from the device, env_step_resolve) without touching
+        // it, so that a CU holds 7 of them instead of 32 waves.  Thirteen streams from 8192
         // resident waves thrash the memory system's open pages; from 1792 they do not: 2^24 envs, same box, interleaved
         // (tools/envstep_ab.hip): 256 threads / no limit 152.5 us = 0.715 of 8 TB/s; 5 / 6 / 7 / 8 / 10 / 12 / 16 waves per CU
         // 148.0 / 132.1 / 132.1 / 133.9 / 134.4 / 141.1 / 151.1 us -- 0.826 at 6-7, above a plain two-stream copy (0.805).
-        // ses_set_tuning "env_step_block" / "env_step_lds_bytes" (0 = the old shape: 256 threads, no reservation).
+        // ses_set_tuning "env_step_block" / "env_step_waves_per_cu" / "env_step_lds_bytes" (-1 = derive; 0 with block 256 = the
+        // old shape: no reservation).
         const EnvStepShape sh = env_step_shape(h, n4);
         if (mode == SES_MODE_FIXED_LENGTH)
             hipLaunchKernelGGL((k_env_step_cartpole_v4<true>), dim3(sh.blocks), dim3(sh.block), sh.lds, h->stream, n4, max_step,
@@ -1448,6 +1487,18 @@ int ses_env_step(ses_handle *h, int32_t n, int32_t mode, float *x, float *xd, fl
                                max_step, x, xd, th, thd, action, ret, status);
     }
     SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
+
+int ses_env_step_shape(ses_handle *h, int32_t *block, int32_t *lds_bytes, int32_t *waves_per_cu)
+{
+    using namespace ses;
+    SES_REQUIRE(h, "ses_env_step_shape: null handle");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    env_step_resolve(h);
+    if (block) *block = h->tune_env_step_block;
+    if (lds_bytes) *lds_bytes = h->env_step_lds_resolved;
+    if (waves_per_cu) *waves_per_cu = h->env_step_wpc;
     return SES_OK;
 }
 

@@ -390,6 +390,12 @@ class HipES:
               "ses_env_step_generic")
         return obs, reward, done
 
+    def env_step_shape(self):
+        """ses_env_step_shape: (threads per workgroup, LDS bytes reserved per workgroup, waves per CU by the occupancy calculator)."""
+        b, l, w = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        check(self._lib.ses_env_step_shape(self._h, ctypes.byref(b), ctypes.byref(l), ctypes.byref(w)), "ses_env_step_shape")
+        return b.value, l.value, w.value
+
     def stream_probe(self, x, xd, th, thd, action, ret, status):
         """ses_stream_probe: the env-step kernel's 13 streams with no arithmetic (values unchanged) -- bench.py's ceiling."""
         n = x.shape[0]

@@ -229,10 +229,27 @@ def test_env_step_wild_states_general_sincos_and_angle_clamp(es, mode):
         assert np.abs(st[2]).max() == np.float32(0.75)           # the clamp was active
 
 
-@pytest.mark.parametrize("block,lds", [(256, 0), (128, 40960), (64, 10240), (256, 65536)])
+def test_env_step_default_shape_is_derived_from_the_device():
+    """The default reservation is a seventh of the device's LDS per CU (no constant in the source): the occupancy calculator
+    must see 7 single-wave workgroups per CU for it, and the waves knob must move it."""
+    from ses import HipES
+    h = HipES("CartPole-v1", 4, 2, True, False, max_step=500, eval_ep_num=1)
+    block, lds, wpc = h.env_step_shape()
+    per_cu = torch.cuda.get_device_properties(0).shared_memory_per_multiprocessor
+    assert block == 64 and wpc == 7, (block, lds, wpc)
+    assert per_cu // 8 < lds <= per_cu // 7, (lds, per_cu)
+    h.set_tuning("env_step_waves_per_cu", 5)
+    assert h.env_step_shape()[2] == 5 and per_cu // 6 < h.env_step_shape()[1] <= per_cu // 5
+    h.set_tuning("env_step_lds_bytes", 0)
+    h.set_tuning("env_step_block", 256)
+    assert h.env_step_shape()[1] == 0 and h.env_step_shape()[2] >= 8
+    h.close()
+
+
+@pytest.mark.parametrize("block,lds", [(64, -1), (256, 0), (128, 40960), (64, 10240), (256, 65536)])
 def test_env_step_launch_shapes_change_no_bit(block, lds):
     """ses_env_step limits its waves in flight with an LDS reservation (knobs env_step_block / env_step_lds_bytes): every
-    shape, the old unlimited one included, returns the bits of the default one -- and of the oracle."""
+    shape -- the derived default (-1), the old unlimited one -- returns the bits of the oracle."""
     from ses import HipES
     n = 70000 + 4 * 37                                            # several workgroups of every shape, a ragged tail
     rng = np.random.RandomState(block + lds)

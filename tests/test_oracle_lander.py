@@ -304,3 +304,55 @@ def test_independent_float64_lander_envelope():
         assert abs(obs[0][0] - obs[1][0]) < 0.03 and abs(obs[0][1] - obs[1][1]) < 0.003 and abs(obs[0][4] - obs[1][4]) < 0.02, (ep, obs)
     assert np.median(gaps) < 1.0, gaps
     assert same_legs >= 18, same_legs      # [19: once the float32 world sleeps with one foot a hair outside the contact skin, 10 points less]
+
+
+def test_the_exact_fixed_point_exits_change_no_bit():
+    """The lander's velocity iterations leave their loop once an iteration has returned every velocity and accumulated
+    impulse bit for bit (main loop: one comparison after iteration 7; time-of-impact sub-step: after every iteration) --
+    ses_b2.h.  oracle/_build/libses_b2_allits.so is the same text compiled with -DB2_RUN_ALL_ITERATIONS, which takes
+    neither exit and runs all 180 iterations everywhere: every observation, reward and termination of 40 episodes --
+    landings with gym's heuristic (touch-downs: time-of-impact sub-steps, contacts, the sleep timer), free falls and
+    main-engine-biased random flights -- must be identical, bit for bit, as must the hidden state at the end."""
+    import ctypes
+    all_its = ctypes.CDLL(os.path.join(os.path.dirname(co.build()), "libses_b2_allits.so"))
+    all_its.o_lander_step.restype = ctypes.c_float
+    assert all_its.o_lander_state_size() == co.lib().o_lander_state_size()
+
+    class AllIts(co.LanderSim):
+        def reset(self, u16):
+            u16, obs = np.ascontiguousarray(u16, np.float32), np.empty(8, np.float32)
+            all_its.o_lander_reset(self._buf, u16.ctypes.data_as(ctypes.c_void_p), obs.ctypes.data_as(ctypes.c_void_p))
+            return obs
+
+        def step(self, a0, a1):
+            obs, done = np.empty(8, np.float32), ctypes.c_int32(0)
+            r = all_its.o_lander_step(self._buf, ctypes.c_float(a0), ctypes.c_float(a1), obs.ctypes.data_as(ctypes.c_void_p),
+                                      ctypes.byref(done))
+            return obs, float(r), bool(done.value)
+
+    rng = np.random.RandomState(11)
+    fast, full = co.LanderSim(), AllIts()
+    steps = touched = asleep = 0
+    for ep in range(40):
+        u = rng.rand(16).astype(np.float32)
+        o1, o2 = fast.reset(u), full.reset(u)
+        assert np.array_equal(o1.view(np.uint32), o2.view(np.uint32)), ep
+        kind = ep % 4
+        for t in range(600):
+            if kind == 0 or kind == 1:
+                a = heuristic(o1)
+            elif kind == 2:
+                a = (0.0, 0.0)
+            else:
+                a = (float(np.tanh(rng.randn() + 0.8)), float(np.tanh(rng.randn() * 1.5)))
+            o1, r1, d1 = fast.step(*a)
+            o2, r2, d2 = full.step(*a)
+            steps += 1
+            touched += int(o1[6] or o1[7])
+            assert np.array_equal(o1.view(np.uint32), o2.view(np.uint32)) and d1 == d2, (ep, t)
+            assert np.float32(r1).view(np.uint32) == np.float32(r2).view(np.uint32), (ep, t, r1, r2)
+            if d1:
+                asleep += int(r1 == 100.0)
+                break
+        assert bytes(fast._buf.raw) == bytes(full._buf.raw), ep      # bodies, joints, manifolds and their impulses, timers
+    assert steps > 5000 and touched > 500 and asleep >= 15, (steps, touched, asleep)
