@@ -5,7 +5,7 @@
 # lines, loop timings.   usage: tools/gpu_final_round.sh [round tag = r03] [fuzz seconds per process = 240]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-TAG=${1:-r03}
+TAG=${1:-r04}
 FUZZ=${2:-240}
 OUT=gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
@@ -49,7 +49,17 @@ SES_OUT=$R/ab/libT.so SES_OBJ=/tmp/objT bash simple-es_amd/csrc/build.sh -DSES_P
 for w in walker lander c3; do SES_LIB_PATH=$R/ab/libT.so python tools/walker_phases.py $w 4096 2>/dev/null; done > $OUT/${TAG}_step_phases.txt
 python tools/c3_breakdown.py > $OUT/${TAG}_c3_breakdown.txt 2>&1
 python tools/lander_step_cost.py > $OUT/${TAG}_lander_step_cost.txt 2>&1
-python tools/time_tail.py > $OUT/${TAG}_time_tail.txt 2>&1
+SES_TAIL_SHAPES=1x4096,2x4096,4x4096,4x8192,4x16384 python tools/time_tail.py > $OUT/${TAG}_time_tail.txt 2>&1
+# the shard form of the tail by kernel at the 8-rank shapes: eight in-process ranks oversubscribe the hardware queues of one GPU
+# (the loop as a whole then runs at the queue scheduler's pace), but a kernel's own duration in the trace does not depend on that
+rm -rf gpurun_out/prof_tail
+SES_TAIL_SHAPES=8x4096,8x8192 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tail -o tail -- python3 tools/time_tail.py > gpurun_out/prof_tail.txt 2>&1
+python tools/tail_by_kernel.py $(find gpurun_out/prof_tail -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_tail_by_kernel.txt 2>&1; cat $OUT/${TAG}_tail_by_kernel.txt
+# bench.py --gpus 2 / 4 rehearsed with the ranks sharing this GPU (gloo control plane, peer-store transport): the multi-rank
+# code path of the bench, NOT a scaling measurement
+for n in 2 4; do
+  SES_BENCH_BACKEND=gloo timeout -k 10 500 python bench.py --gpus $n --steps 100 --warmup 20 --blocks 9 --no-roofline --no-cpu-baseline --loop-generations 300 > $OUT/${TAG}_bench_rehearsal_gloo_${n}ranks_one_gpu.json 2>> $OUT/bench.err
+done
 # gpurun copies gpurun_out/ back only below 64 MiB: the raw rocprofv3 directories stay on the box
 find gpurun_out -mindepth 1 -maxdepth 1 ! -name final -exec rm -rf {} +
 du -sh gpurun_out | cut -f1
