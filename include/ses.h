@@ -194,9 +194,9 @@ int ses_env_step_generic(ses_handle *h, void *state, const void *action, int32_t
                          int32_t *done);
 
 /* The launch shape ses_env_step (and ses_stream_probe) use on this device with the current knobs: threads per workgroup, the
- * LDS bytes each workgroup reserves, and the waves per CU the HIP occupancy calculator gives that shape (0: unknown).  Any
- * pointer may be NULL. */
-int ses_env_step_shape(ses_handle *h, int32_t *block, int32_t *lds_bytes, int32_t *waves_per_cu);
+ * LDS bytes each workgroup reserves, the waves per CU the HIP occupancy calculator gives that shape (0: unknown), and the
+ * device's LDS per CU the default reservation is derived from.  Any pointer may be NULL. */
+int ses_env_step_shape(ses_handle *h, int32_t *block, int32_t *lds_bytes, int32_t *waves_per_cu, int32_t *lds_per_cu);
 
 /* Measurement aid for the roofline of ses_env_step (no reference counterpart): the same 13 streams -- 7 x 16-byte
  * non-temporal loads and 6 x 16-byte non-temporal stores per lane over the same arrays, same grid -- with no arithmetic

@@ -1490,7 +1490,7 @@ int ses_env_step(ses_handle *h, int32_t n, int32_t mode, float *x, float *xd, fl
     return SES_OK;
 }
 
-int ses_env_step_shape(ses_handle *h, int32_t *block, int32_t *lds_bytes, int32_t *waves_per_cu)
+int ses_env_step_shape(ses_handle *h, int32_t *block, int32_t *lds_bytes, int32_t *waves_per_cu, int32_t *lds_per_cu)
 {
     using namespace ses;
     SES_REQUIRE(h, "ses_env_step_shape: null handle");
@@ -1499,6 +1499,7 @@ int ses_env_step_shape(ses_handle *h, int32_t *block, int32_t *lds_bytes, int32_
     if (block) *block = h->tune_env_step_block;
     if (lds_bytes) *lds_bytes = h->env_step_lds_resolved;
     if (waves_per_cu) *waves_per_cu = h->env_step_wpc;
+    if (lds_per_cu) *lds_per_cu = h->lds_per_cu;
     return SES_OK;
 }
 

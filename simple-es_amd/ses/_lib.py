@@ -89,7 +89,7 @@ SIGNATURES = {
     "ses_env_obs_width": [_vp],
     "ses_env_reset": [_vp, _vp, _i32, _vp, _vp],
     "ses_env_step_generic": [_vp, _vp, _vp, _i32, _vp, _vp, _vp],
-    "ses_env_step_shape": [_vp, _vp, _vp, _vp],
+    "ses_env_step_shape": [_vp, _vp, _vp, _vp, _vp],
     "ses_stream_probe": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ses_rollout": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "ses_rank_center": [_vp, _vp, _i32, _vp, _vp, _vp],

@@ -391,10 +391,12 @@ class HipES:
         return obs, reward, done
 
     def env_step_shape(self):
-        """ses_env_step_shape: (threads per workgroup, LDS bytes reserved per workgroup, waves per CU by the occupancy calculator)."""
-        b, l, w = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
-        check(self._lib.ses_env_step_shape(self._h, ctypes.byref(b), ctypes.byref(l), ctypes.byref(w)), "ses_env_step_shape")
-        return b.value, l.value, w.value
+        """ses_env_step_shape: (threads per workgroup, LDS bytes reserved per workgroup, waves per CU by the occupancy
+        calculator, the device's LDS bytes per CU)."""
+        b, l, w, c = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        check(self._lib.ses_env_step_shape(self._h, ctypes.byref(b), ctypes.byref(l), ctypes.byref(w), ctypes.byref(c)),
+              "ses_env_step_shape")
+        return b.value, l.value, w.value, c.value
 
     def stream_probe(self, x, xd, th, thd, action, ret, status):
         """ses_stream_probe: the env-step kernel's 13 streams with no arithmetic (values unchanged) -- bench.py's ceiling."""

@@ -53,7 +53,7 @@ SES_TAIL_SHAPES=1x4096,2x4096,4x4096,4x8192,4x16384 python tools/time_tail.py > 
 # the shard form of the tail by kernel at the 8-rank shapes: eight in-process ranks oversubscribe the hardware queues of one GPU
 # (the loop as a whole then runs at the queue scheduler's pace), but a kernel's own duration in the trace does not depend on that
 rm -rf gpurun_out/prof_tail
-SES_TAIL_SHAPES=8x4096,8x8192 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tail -o tail -- python3 tools/time_tail.py > gpurun_out/prof_tail.txt 2>&1
+(cd /tmp && export TMPDIR=/tmp && SES_TAIL_SHAPES=8x4096,8x8192 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_tail -- python3 $R/tools/time_tail.py > $R/gpurun_out/prof_tail.txt 2>&1)
 python tools/tail_by_kernel.py $(find gpurun_out/prof_tail -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_tail_by_kernel.txt 2>&1; cat $OUT/${TAG}_tail_by_kernel.txt
 # bench.py --gpus 2 / 4 rehearsed with the ranks sharing this GPU (gloo control plane, peer-store transport): the multi-rank
 # code path of the bench, NOT a scaling measurement
