@@ -101,7 +101,9 @@ int ses_sync(ses_handle *h);
  * peer-store transport is attached -- for measuring one against the other), "comm_p2p_timeout_ms" (how long a peer-store
  * exchange waits for a peer's shard; 0 = default 60000), "comm_p2p_keep_going" (1: after a time-out later exchanges still
  * run instead of failing; the host polls ses_comm_p2p_status, agrees with the other ranks and rolls back -- ESLoop.run()),
- * "openai_sharded_tail" (default 1; 0: ses_openai_sharded_ok answers no, sharded runs keep the replicated openai_es tail).
+ * "openai_sharded_tail" (default 1; 0: ses_openai_sharded_ok answers no, sharded runs keep the replicated openai_es tail),
+ * "openai_granule_exchange" (default 1; 0: ses_openai_generation_sharded all-gathers its chunk partials with a launch of their
+ * own also on the peer-store transport, as it does over RCCL -- for measuring one against the other).
  * The library itself reads no environment variable. */
 int ses_set_tuning(ses_handle *h, const char *name, int32_t value);
 /* Timing without events: from now on the last kernel of every ses_rollout (the episode mean: end of the rollout phase)
@@ -244,9 +246,12 @@ int ses_openai_generation(ses_handle *h, const float *fitness, int32_t n, uint64
 /* The same generation when the population is sharded over `world` ranks (loop.py:66-84 with one process per GPU) WITHOUT
  * every rank repeating the O(n) work: this rank ranks only its own rows [first_row, first_row + n_rows) against the gathered
  * fitness (n <= 8192: counting rank; above: every workgroup sorts one 1024-key tile and searches it for 1024 own rows) and
- * accumulates the ES gradient over its own 1024-row chunks only; the ranks then all-gather their [chunks per rank, P] chunk
- * partials -- with the candidates for max(fitness) behind them -- through `comm`'s transport (ses_allgather_fitness: peer
- * stores or RCCL; 58 KB in total at 65 536 x 226), and the unchanged ordered update adds the chunks in ascending order.
+ * accumulates the ES gradient over its own 1024-row chunks only; the ranks then exchange their [chunks per rank, P] chunk
+ * partials -- with the candidates for max(fitness) behind them -- through `comm`'s transport (58 KB in total at 65 536 x 226)
+ * and the unchanged ordered update adds the chunks in ascending order.  On the peer-store transport the exchange needs no
+ * launch: the gradient kernel stores every partial as one 8-byte {exchange number, value} granule straight into every rank's
+ * mailbox and the update kernel polls the granules where they land (the data is the flag); over RCCL, or when a mailbox
+ * section cannot hold the granules, the partials are all-gathered as floats by ses_allgather_fitness in between.
  * Bit-identical to ses_openai_generation for ANY world size, because a rank's slot of per_rank = ceil(n / world) rows is a
  * whole number of the gradient's 1024-row chunks -- that is the condition; ses_openai_sharded_ok tells (1 / 0) whether it
  * holds and `comm` (a handle on the same device and stream that owns a transport of `world` ranks which takes the payload)

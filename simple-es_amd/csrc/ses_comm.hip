@@ -61,6 +61,10 @@ struct ses_p2p {
     bool attached;
     bool local;                             // attached to handles of this process (ses_comm_p2p_attach_local): nothing mapped, nothing to close
     size_t bytes, flag_offset;              // mailbox layout: float data[2][world][max_per_rank] | uint32 flags[2][world][splits_max] | seen mask
+                                            //                 | u64 granules[2][world][max_per_rank / 2]
+    size_t gran_offset;                     // the granule area: {sequence, value} words of the exchanges kernels do themselves (comm_p2p_granules_begin);
+                                            // an area and a sequence of its own, so that no float of a flag-based exchange is ever read as a tag
+    uint32_t gseq;                          // granule exchanges issued so far
     void *own;                              // this rank's mailbox (device memory, fine-grained)
     void *peer[ses::P2P_MAX_WORLD];         // peer[r]: rank r's mailbox as mapped here (peer[rank] == own)
     uint32_t seq;                           // exchanges issued so far
@@ -189,6 +193,34 @@ void comm_p2p_set_timeout(ses_handle *h)
         h->p2p->timeout_ticks = (unsigned long long)(h->tune_comm_p2p_timeout_ms > 0 ? h->tune_comm_p2p_timeout_ms : 60000) * P2P_TICKS_PER_MS;
 }
 
+int comm_p2p_granules_begin(ses_handle *comm, int granules, P2pGranuleView *v)
+{
+    static_assert(P2P_GRANULE_MAX_WORLD == P2P_MAX_WORLD, "world limit");
+    ses_p2p *p = comm ? comm->p2p : nullptr;
+    if (!p || !p->attached || granules < 1 || granules > p->max_per_rank / 2 || (comm->tune_comm_force_rccl && comm->comm))
+        return set_error(SES_ERR_UNSUPPORTED, "granule exchange: no peer-store transport for %d granules per rank", granules);
+    if (*(volatile uint32_t *)p->err_host != 0u && !comm->tune_comm_p2p_keep_going)
+        return set_error(SES_ERR_COMM, "peer-store exchange: an earlier exchange timed out waiting for rank mask 0x%x (its output was "
+                         "NaN-filled); detach the transport (ses_comm_p2p_detach) to continue over RCCL", *(volatile uint32_t *)p->err_host);
+    if (p->gseq == 0x7FFFFFFFu)
+        return set_error(SES_ERR_COMM, "peer-store sequence exhausted; detach and attach the transport again");
+    p->gseq += 1;
+    const int slot = (int)(p->gseq & 1u);
+    // granules[2][world][max_per_rank / 2]: section (slot, source rank).  Two slots alternate as in the flag-based exchange: a
+    // peer's granules of exchange s + 2 can only come after it has finished s + 1, which needed this rank's granules of s + 1,
+    // which this rank's stream issues after its reads of s.
+    const size_t section = (size_t)p->max_per_rank / 2;
+    for (int r = 0; r < p->world; ++r)
+        v->dst[r] = (unsigned long long *)((char *)p->peer[r] + p->gran_offset) + ((size_t)slot * p->world + p->rank) * section;
+    v->src = (const unsigned long long *)((char *)p->own + p->gran_offset) + (size_t)slot * p->world * section;
+    v->section = (int)section;
+    v->rank = p->rank; v->world = p->world;
+    v->seq = p->gseq;
+    v->timeout_ticks = p->timeout_ticks;
+    v->err = p->err_dev; v->err_seen = p->err_seen;
+    return SES_OK;
+}
+
 int comm_release(ses_handle *h)
 {
     if (h->comm && g_rccl.CommDestroy) {
@@ -281,7 +313,8 @@ int ses_comm_p2p_export(ses_handle *h, int32_t rank, int32_t world, int32_t max_
     p->splits_max = ceil_div(p->max_per_rank, P2P_SPLIT);
     p->flag_offset = (sizeof(float) * 2 * (size_t)world * p->max_per_rank + 255) / 256 * 256;
     const size_t seen_offset = (p->flag_offset + sizeof(uint32_t) * 2 * (size_t)world * p->splits_max + 255) / 256 * 256;
-    p->bytes = seen_offset + 256;
+    p->gran_offset = seen_offset + 256;
+    p->bytes = p->gran_offset + sizeof(unsigned long long) * 2 * (size_t)world * (p->max_per_rank / 2);
     hipError_t e = hipExtMallocWithFlags(&p->own, p->bytes, hipDeviceMallocUncached);
     if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p->own, p->bytes, hipDeviceMallocFinegrained); }
     if (e != hipSuccess) {

@@ -133,6 +133,7 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
         h->lds_per_cu = lds;
     }
     h->tune_openai_sharded_tail = 1;
+    h->tune_openai_granules = 1;
     h->tune_es_final_max_chunks = 0;          // measured: the wave-per-parameter update launch beats the in-kernel finisher
     *out = h;
     return SES_OK;
@@ -163,7 +164,8 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"comm_force_rccl", &ses_handle::tune_comm_force_rccl, 0, 1},
                                  {"comm_p2p_timeout_ms", &ses_handle::tune_comm_p2p_timeout_ms, 0, 1 << 30},
                                  {"comm_p2p_keep_going", &ses_handle::tune_comm_p2p_keep_going, 0, 1},
-                                 {"openai_sharded_tail", &ses_handle::tune_openai_sharded_tail, 0, 1}};
+                                 {"openai_sharded_tail", &ses_handle::tune_openai_sharded_tail, 0, 1},
+                                 {"openai_granule_exchange", &ses_handle::tune_openai_granules, 0, 1}};
     for (const Knob &k : knobs) {
         if (std::strcmp(k.name, name) == 0) {
             SES_REQUIRE(value >= k.lo && value <= k.hi, "ses_set_tuning: %s = %d outside [%d, %d]", name, value, k.lo, k.hi);

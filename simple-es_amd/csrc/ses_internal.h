@@ -54,6 +54,8 @@ struct ses_handle {
     int tune_lander_per_wave;      // offspring per wave of the lockstep lander rollout: 0 = by population size, 1 / 2 / 4
     int tune_comm_p2p_timeout_ms;  // how long a peer-store exchange waits for a peer (0 = the default, 60 s)
     int tune_comm_p2p_keep_going;  // 1: exchanges continue after a time-out (the host polls ses_comm_p2p_status and recovers)
+    int tune_openai_granules;      // 0: the shard form all-gathers its chunk partials as floats with a launch of its own also on the
+                                   // peer-store transport (default 1: {sequence, value} granules stored by the gradient kernel itself)
     int tune_openai_sharded_tail;  // 0: ses_openai_sharded_ok says no (sharded runs use the replicated openai_es tail; A/B runs)
 };
 
@@ -79,6 +81,23 @@ int set_error(int code, const char *fmt, ...);
     } while (0)
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// A view of the peer-store mailboxes for kernels that exchange 8-byte {sequence, value} GRANULES themselves (the shard form
+// of the openai_es tail: the gradient kernel stores its chunk partials straight into every rank's mailbox, the update
+// kernel polls them -- the data is the flag, no exchange launch, no fence).  One aligned 8-byte store carries both words.
+constexpr int P2P_GRANULE_MAX_WORLD = 16;
+struct P2pGranuleView {
+    unsigned long long *dst[P2P_GRANULE_MAX_WORLD];   // dst[r]: where THIS rank's granules go in rank r's mailbox (r = own rank included)
+    const unsigned long long *src;                    // this rank's mailbox, the slot of this exchange: rank s's granules at src + s * section
+    int section;                                      // granules per (slot, source rank) section
+    int rank, world;
+    uint32_t seq;                                     // the tag of this exchange
+    unsigned long long timeout_ticks;
+    uint32_t *err, *err_seen;                         // as k_allgather_p2p: host-visible mask, its copy in device memory
+};
+// reserves the next exchange of `comm`'s peer-store transport for a granule exchange of `granules` per rank; SES_ERR_UNSUPPORTED
+// when the transport is not attached or a section cannot hold them, SES_ERR_COMM after an unrecovered time-out
+int comm_p2p_granules_begin(ses_handle *comm, int granules, P2pGranuleView *view);
 
 int ensure_episode_scratch(ses_handle *h, size_t episodes);
 int ensure_reduce_scratch(ses_handle *h, size_t bytes);

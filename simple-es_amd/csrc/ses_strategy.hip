@@ -364,6 +364,75 @@ __global__ __launch_bounds__(256) void k_es_grad_partial(const double *__restric
 // One wavefront per parameter: lane c fetches the partial of chunk c (all chunks in flight at once), then the wave adds
 // them in ascending chunk order through v_readlane -- the same sum, in the same order, as a thread walking the chunks,
 // without its chain of dependent L2 reads (32 chunks: 9.9 -> ~3 us).
+__device__ __forceinline__ void granule_store(unsigned long long *dst, uint32_t seq, uint32_t value_bits)
+{
+    // ONE aligned 8-byte store carries the value and the tag of the exchange it belongs to: whoever reads the tag it waits
+    // for has the value (no flag, no fence); system scope: the mailbox may be another GPU's memory
+    __hip_atomic_store(dst, ((unsigned long long)value_bits << 32) | (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// waits for the granule of exchange v.seq at `src` (a section of THIS rank's mailbox written by rank `from`): its value bits,
+// or NaN after the time-out / when the word already carries a LATER exchange's tag (the peer gave up on this rank and moved
+// on) -- with rank `from`'s bit set in the error words, as k_allgather_p2p does
+__device__ __forceinline__ uint32_t granule_wait(const unsigned long long *src, const P2pGranuleView &v, int from)
+{
+    const unsigned long long t0 = real_time();
+    unsigned long long limit = v.timeout_ticks;
+    bool known_late = false;
+    for (;;) {
+        const unsigned long long g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t tag = (uint32_t)g;
+        if (tag == v.seq) return (uint32_t)(g >> 32);
+        if (!known_late) {                                            // (read once, on the slow path only)
+            known_late = true;
+            const uint32_t seen = __hip_atomic_load(v.err_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (((seen >> (from & 31)) & 1u) && limit > 200000ull) limit = 200000ull;      // 2 ms for a peer that was late before
+        }
+        if ((int32_t)(tag - v.seq) > 0 || real_time() - t0 > limit) {
+            atomicOr_system(v.err, 1u << (from & 31));
+            atomicOr(v.err_seen, 1u << (from & 31));
+            return 0x7FC00000u;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// The update over granules (ses_openai_generation_sharded on the peer-store transport): lane c WAITS for the granule of
+// chunk c -- rank c / cl's section of this rank's mailbox, written by that rank's gradient kernel -- instead of loading a
+// float from an all-gathered array; the ordered sum and Adam are k_es_apply's.  A chunk that does not arrive in time is NaN
+// and marks its rank in the error words (the host's recovery is ESLoop.run's, as for the fitness exchange).
+__global__ __launch_bounds__(256) void k_es_apply_granules(P2pGranuleView gv, int chunks, int P, int P4, float update_factor,
+                                                           double adam_a, const float *mu, const float *m, const float *v,
+                                                           float *mu_out, float *m_out, float *v_out, int cl,
+                                                           float *__restrict__ best)
+{
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= P) return;                                                  // wave-uniform
+    if (p == 0) {                                                        // the candidates for max(fitness): exactly one is there
+        for (int c = lane; c < gv.world * cl; c += 64) {
+            const uint32_t u = granule_wait(gv.src + (size_t)(c / cl) * gv.section + (size_t)cl * P4 + c % cl, gv, c / cl);
+            if (u != 0xFFFFFFFFu && best) *best = __builtin_bit_cast(float, u);
+        }
+    }
+    float sum = 0.0f;
+    for (int base = 0; base < chunks; base += 64) {
+        const int cm = base + lane;
+        float mine = 0.0f;
+        if (cm < chunks)
+            mine = __builtin_bit_cast(float, granule_wait(gv.src + (size_t)(cm / cl) * gv.section + (size_t)(cm % cl) * P4 + p, gv, cm / cl));
+        const int cnt = chunks - base < 64 ? chunks - base : 64;
+        for (int c = 0; c < cnt; ++c) {
+            const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), c));
+            sum = (base + c == 0) ? x : sum + x;
+        }
+    }
+    if (lane != 0) return;
+    const float g = sum * update_factor;  // offspring_strategies.py:414
+    float muv = mu[p], mv = m[p], vv = v[p];
+    adam_apply(g, adam_a, muv, mv, vv);
+    mu_out[p] = muv; m_out[p] = mv; v_out[p] = vv;
+}
+
 __global__ __launch_bounds__(256) void k_es_apply(const float *__restrict__ partial, int chunks, int P, int P4,
                                                   float update_factor, double adam_a, const float *mu, const float *m,
                                                   const float *v, float *mu_out, float *m_out, float *v_out,
@@ -418,7 +487,7 @@ __global__ __launch_bounds__(256) void k_es_apply(const float *__restrict__ part
 // reduction: writers fence before taking their ticket, the finisher fences before it reads and re-arms the counter).
 // (Measured: 11.9 us per launch against 7.4 for the plain partial-sum kernel -- the agent-scope fences flush the XCD's L2
 // -- i.e. what the separate update launch it replaces cost.)
-template <bool FINAL>
+template <bool FINAL, bool GRAN = false>
 __global__ __launch_bounds__(256) void k_es_grad_partial_ranked(const int32_t *__restrict__ rank,
                                                                 const float *__restrict__ fitness, int n, int skip_row0,
                                                                 uint64_t seed, uint64_t gen, int P4,
@@ -427,8 +496,13 @@ __global__ __launch_bounds__(256) void k_es_grad_partial_ranked(const int32_t *_
                                                                 float update_factor, double adam_a, const float *mu_in,
                                                                 const float *m_in, const float *v_in, float *mu_out,
                                                                 float *m_out, float *v_out, int first, int row_end,
-                                                                uint32_t *__restrict__ cand_out)
+                                                                uint32_t *__restrict__ cand_out, P2pGranuleView gv = P2pGranuleView{},
+                                                                int cl = 0)
 {
+    // GRAN: the chunk partials (and the candidate) do not go to partial[] / cand_out[] but, as {sequence, value} granules,
+    // straight into the mailbox of EVERY rank (peer stores over xGMI; this rank's own mailbox included): granule
+    // blockIdx.y * P4 + 4 q + t of this rank's section, the candidates behind the cl * P4 partials.  The update kernel of each
+    // rank polls them where they land: no exchange launch between the two kernels.
     // Shard form (ses_openai_generation_sharded): blockIdx.y counts the chunks of THIS rank's rows [first, row_end) --
     // first is a multiple of ES_CHUNK, so they are chunks of the global population --, rank[] is indexed from `first`, and
     // the chunk that holds the row of rank 0 reports its fitness as a bit pattern in cand_out[chunk] (0xFFFFFFFF = "not
@@ -442,7 +516,7 @@ __global__ __launch_bounds__(256) void k_es_grad_partial_ranked(const int32_t *_
     const int row1 = row0 + ES_CHUNK < row_end ? row0 + ES_CHUNK : row_end;
     const double nm1 = (double)(n - 1);
     const double sd = sqrt((double)(n + 1) / (12.0 * nm1));           // closed-form std of the rank grid
-    if (cand_out && q == 0) {                                          // uniform per workgroup
+    if ((cand_out || GRAN) && q == 0) {                                // uniform per workgroup
         if (threadIdx.x == 0) cand = 0xFFFFFFFFu;
         __syncthreads();
     }
@@ -451,7 +525,7 @@ __global__ __launch_bounds__(256) void k_es_grad_partial_ranked(const int32_t *_
         const int r = rank[i - first];
         if (q == 0 && r == 0) {                                        // max(rewards), loop.py:82-84 `best_reward`
             if (best) *best = fitness[i];
-            if (cand_out) cand = f2u(fitness[i]);
+            if (cand_out || GRAN) cand = f2u(fitness[i]);
         }
         if (skip_row0 && i == 0) continue;
         const double centred = ((double)(n - 1 - r) / nm1) - 0.5;      // offspring_strategies.py:394-396
@@ -470,6 +544,14 @@ __global__ __launch_bounds__(256) void k_es_grad_partial_ranked(const int32_t *_
             for (int l = 0; l < 4; ++l) red[l][threadIdx.x] = red[l][threadIdx.x] + red[l][threadIdx.x + s];
         }
         __syncthreads();
+    }
+    if (GRAN) {
+        const int peer = threadIdx.x >> 2, comp = threadIdx.x & 3;
+        if (peer < gv.world) {                                         // thread (peer, component): one 8-byte store each
+            granule_store(gv.dst[peer] + (size_t)blockIdx.y * P4 + 4 * q + comp, gv.seq, f2u(red[comp][0]));
+            if (q == 0 && comp == 0) granule_store(gv.dst[peer] + (size_t)cl * P4 + blockIdx.y, gv.seq, cand);
+        }
+        return;
     }
     if (threadIdx.x < 4) partial[(size_t)blockIdx.y * P4 + 4 * q + threadIdx.x] = red[threadIdx.x][0];
     if (cand_out && q == 0 && threadIdx.x == 0) cand_out[blockIdx.y] = cand;
@@ -807,8 +889,23 @@ static int openai_generation_impl(ses_handle *h, ses_handle *comm, const float *
         // a separate small launch finishes the update; this layout's partial[] may lie over the ticket counter of a
         // smaller population's layout, so a cached "counter is zero" no longer holds
         h->counter_armed = nullptr;
-        if (sharded) {
-            // every chunk of the slot is written, also the ones past the end of a ragged last shard (zeros, no candidate)
+        P2pGranuleView gv;
+        // (only while the polling update kernel is a small grid -- P <= 1024: every policy but the GRU ones.  Its workgroups
+        //  spin until the peers' granules are there; ranks that SHARE a GPU -- the test rigs -- must not fill it with waiters
+        //  and starve the producers they wait for.  Across GPUs there is no such coupling, but one rule serves both.)
+        const int grc = (sharded && h->tune_openai_granules && quads <= 256) ? comm_p2p_granules_begin(comm, cl * P4 + cl, &gv)
+                                                                              : SES_ERR_UNSUPPORTED;
+        if (sharded && grc == SES_ERR_COMM) return grc;
+        if (sharded && grc == SES_OK) {
+            // peer stores straight from the gradient kernel, the update polls: no launch between them.  Every chunk of the
+            // slot is written, also the ones past the end of a ragged last shard (zeros, no candidate)
+            hipLaunchKernelGGL((k_es_grad_partial_ranked<false, true>), dim3(quads, cl), dim3(256), 0, h->stream, rank, fitness, n, 1,
+                               seed, gen, P4, partial, (float *)nullptr, counter, chunks, h->P, (float)uf, adam_a, mu_in, m_in,
+                               v_in, mu_out, m_out, v_out, first, first + n_own, (uint32_t *)nullptr, gv, cl);
+            hipLaunchKernelGGL(k_es_apply_granules, dim3(ceil_div(h->P, 4)), dim3(256), 0, h->stream, gv, chunks, h->P, P4,
+                               (float)uf, adam_a, mu_in, m_in, v_in, mu_out, m_out, v_out, cl, best);
+        } else if (sharded) {
+            // (RCCL, or a payload beyond a mailbox section: the partials are all-gathered as floats by a launch of their own)
             hipLaunchKernelGGL((k_es_grad_partial_ranked<false>), dim3(quads, cl), dim3(256), 0, h->stream, rank, fitness, n, 1,
                                seed, gen, P4, partial, (float *)nullptr, counter, chunks, h->P, (float)uf, adam_a, mu_in, m_in,
                                v_in, mu_out, m_out, v_out, first, first + n_own, (uint32_t *)(partial + (size_t)cl * P4));

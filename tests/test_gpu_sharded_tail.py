@@ -17,7 +17,7 @@ SRC = os.path.join(ROOT, "simple-es_amd")
 
 WORKER = textwrap.dedent("""
     import os, sys
-    world, per, missing, P_gru = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    world, per, missing, P_gru, granules = (int(v) for v in sys.argv[1:6])
     os.environ["GPU_MAX_HW_QUEUES"] = str(max(world + 1, 4))      # a hardware queue per stream: an exchange kernel waits for its peers'
     import numpy as np, torch
     sys.path[:0] = [%r, %r]
@@ -29,6 +29,8 @@ WORKER = textwrap.dedent("""
     P = ref.P
     for r, es in enumerate(ranks):
         es.set_tuning("comm_p2p_timeout_ms", 5000)
+        es.set_tuning("openai_granule_exchange", granules)   # 1: the gradient kernel stores {sequence, value} granules into the
+                                                             # peers' mailboxes and the update polls them; 0: float all-gather launch
         es.comm_p2p_export(r, world, 65536)
     for es in ranks:
         es.comm_p2p_attach_local(ranks)
@@ -70,14 +72,15 @@ WORKER = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("world,per,missing,gru", [(8, 4096, 0, 0), (8, 8192, 0, 0), (16, 4096, 5, 0), (2, 1024, 1, 0),
-                                                   (4, 2048, 0, 1), (8, 1024, 7, 0)],
+@pytest.mark.parametrize("world,per,missing,gru,granules",
+                         [(8, 4096, 0, 0, 1), (8, 8192, 0, 0, 1), (16, 4096, 5, 0, 1), (2, 1024, 1, 0, 1), (4, 2048, 0, 1, 1),
+                          (8, 1024, 7, 0, 1), (4, 4096, 3, 0, 0), (2, 1024, 0, 1, 0)],
                          ids=["8x4096_weak8", "8x8192_c4", "16x4096_ragged", "2x1024_counting_rank_ragged", "4x2048_gru_P6562",
-                              "8x1024_counting_rank_ragged"])
-def test_sharded_tail_equals_replicated_tail_bitwise(tmp_path, world, per, missing, gru):
+                              "8x1024_counting_rank_ragged", "4x4096_ragged_float_allgather", "2x1024_gru_float_allgather"])
+def test_sharded_tail_equals_replicated_tail_bitwise(tmp_path, world, per, missing, gru, granules):
     script = tmp_path / "tail.py"
     script.write_text(WORKER % (ROOT, SRC))
-    run = subprocess.run(["timeout", "-k", "10", "300", sys.executable, str(script), str(world), str(per), str(missing), str(gru)],
+    run = subprocess.run(["timeout", "-k", "10", "300", sys.executable, str(script), str(world), str(per), str(missing), str(gru), str(granules)],
                          capture_output=True, text=True, timeout=400)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
     assert run.stdout.strip().endswith(f"ok {world} {per} {world * per - missing}")
