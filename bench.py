@@ -665,15 +665,19 @@ def run_rank(args):
             have_p2p = owner is not None and owner.comm_route()[0] == world
             have_rccl = owner is not None and owner.comm_route()[2] == world
             for label, floats in (("16KB", 4096), ("128KB", 32768)):
-                micro[label] = {"p2p_store_us": "absent", "rccl_us": "absent"}     # a transport that could not be set up says so
+                micro[label] = {"p2p_store_us": "absent", "p2p_store_granules_us": "absent", "rccl_us": "absent"}   # a transport that could not be set up says so
             if owner is not None:
                 for label, floats in (("16KB", 4096), ("128KB", 32768)):
                     shard_t = torch.full((floats,), float(rank), device=owner.device)
                     out_t = owner.empty(world * floats)
-                    for name, on, force in (("p2p_store_us", have_p2p, 0), ("rccl_us", have_rccl, 1)):
+                    # p2p_store_us: the default kernel (data + sequence words, release / acquire); p2p_store_granules_us: 8-byte
+                    # {exchange number, value} granules, the data as its own flag (knob "comm_granule_allgather")
+                    for name, on, force, gran in (("p2p_store_us", have_p2p, 0, 0), ("p2p_store_granules_us", have_p2p, 0, 1),
+                                                  ("rccl_us", have_rccl, 1, 0)):
                         if not on:
                             continue
                         owner.set_tuning("comm_force_rccl", force)
+                        owner.set_tuning("comm_granule_allgather", gran)
                         for _ in range(10):
                             owner.allgather_fitness(shard_t, out=out_t)
                         torch.cuda.synchronize(); dist.barrier()
@@ -690,6 +694,7 @@ def run_rank(args):
                         micro[label][name] = round(float(t.item()), 2)
                         micro[label]["correct"] = micro[label].get("correct", True) and ok
                     owner.set_tuning("comm_force_rccl", 0)
+                    owner.set_tuning("comm_granule_allgather", 0)
             result["allgather_microbench"] = dict(micro, ranks=world, transports={"p2p_store": "attached" if have_p2p else "absent",
                                                                                     "rccl": "attached" if have_rccl else "absent"},
                                                   note="100 back-to-back ses_allgather_fitness per transport, max over ranks, us per exchange")

@@ -103,7 +103,11 @@ int ses_sync(ses_handle *h);
  * run instead of failing; the host polls ses_comm_p2p_status, agrees with the other ranks and rolls back -- ESLoop.run()),
  * "openai_sharded_tail" (default 1; 0: ses_openai_sharded_ok answers no, sharded runs keep the replicated openai_es tail),
  * "openai_granule_exchange" (default 1; 0: ses_openai_generation_sharded all-gathers its chunk partials with a launch of their
- * own also on the peer-store transport, as it does over RCCL -- for measuring one against the other).
+ * own also on the peer-store transport, as it does over RCCL -- for measuring one against the other),
+ * "comm_granule_allgather" (default 0; 1: ses_allgather_fitness over the peer-store transport moves 8-byte {exchange number,
+ * value} granules -- the data is its own flag -- while the shard fits half a mailbox section.  Measured slower for a whole
+ * fitness shard, 12.4 us against 6.3 at 4096 floats; it is how a rank that does nothing else answers the granule exchange of
+ * ses_openai_generation_sharded, tools/time_tail.py).
  * The library itself reads no environment variable. */
 int ses_set_tuning(ses_handle *h, const char *name, int32_t value);
 /* Timing without events: from now on the last kernel of every ses_rollout (the episode mean: end of the rollout phase)

@@ -54,6 +54,9 @@ struct ses_handle {
     int tune_lander_per_wave;      // offspring per wave of the lockstep lander rollout: 0 = by population size, 1 / 2 / 4
     int tune_comm_p2p_timeout_ms;  // how long a peer-store exchange waits for a peer (0 = the default, 60 s)
     int tune_comm_p2p_keep_going;  // 1: exchanges continue after a time-out (the host polls ses_comm_p2p_status and recovers)
+    int tune_comm_granules;        // 1: ses_allgather_fitness over the peer-store transport moves {sequence, value} granules (no flag, no fence)
+                                   // while a shard fits half a mailbox section; 0 (default): the kernel with sequence words -- for a whole
+                                   // shard the per-float stores and polls cost more than the one release / acquire round they save
     int tune_openai_granules;      // 0: the shard form all-gathers its chunk partials as floats with a launch of its own also on the
                                    // peer-store transport (default 1: {sequence, value} granules stored by the gradient kernel itself)
     int tune_openai_sharded_tail;  // 0: ses_openai_sharded_ok says no (sharded runs use the replicated openai_es tail; A/B runs)
@@ -98,6 +101,42 @@ struct P2pGranuleView {
 // reserves the next exchange of `comm`'s peer-store transport for a granule exchange of `granules` per rank; SES_ERR_UNSUPPORTED
 // when the transport is not attached or a section cannot hold them, SES_ERR_COMM after an unrecovered time-out
 int comm_p2p_granules_begin(ses_handle *comm, int granules, P2pGranuleView *view);
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ void granule_store(unsigned long long *dst, uint32_t seq, uint32_t value_bits)
+{
+    // ONE aligned 8-byte store carries the value and the tag of the exchange it belongs to: whoever reads the tag it waits
+    // for has the value (no flag, no fence); system scope: the mailbox may be another GPU's memory
+    __hip_atomic_store(dst, ((unsigned long long)value_bits << 32) | (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// waits for the granule of exchange v.seq at `src` (a section of THIS rank's mailbox written by rank `from`): its value bits,
+// or NaN after the time-out / when the word already carries a LATER exchange's tag (the peer gave up on this rank and moved
+// on) -- with rank `from`'s bit set in the error words, as k_allgather_p2p does
+__device__ __forceinline__ uint32_t granule_wait(const unsigned long long *src, const P2pGranuleView &v, int from)
+{
+    const unsigned long long t0 = real_time();
+    unsigned long long limit = v.timeout_ticks;
+    bool known_late = false;
+    for (;;) {
+        const unsigned long long g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t tag = (uint32_t)g;
+        if (tag == v.seq) return (uint32_t)(g >> 32);
+        if (!known_late) {                                            // (read once, on the slow path only)
+            known_late = true;
+            const uint32_t seen = __hip_atomic_load(v.err_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (((seen >> (from & 31)) & 1u) && limit > 200000ull) limit = 200000ull;      // 2 ms for a peer that was late before
+        }
+        if ((int32_t)(tag - v.seq) > 0 || real_time() - t0 > limit) {
+            atomicOr_system(v.err, 1u << (from & 31));
+            atomicOr(v.err_seen, 1u << (from & 31));
+            return 0x7FC00000u;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+#endif
 
 int ensure_episode_scratch(ses_handle *h, size_t episodes);
 int ensure_reduce_scratch(ses_handle *h, size_t bytes);

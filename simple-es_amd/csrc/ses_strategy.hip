@@ -364,39 +364,6 @@ __global__ __launch_bounds__(256) void k_es_grad_partial(const double *__restric
 // One wavefront per parameter: lane c fetches the partial of chunk c (all chunks in flight at once), then the wave adds
 // them in ascending chunk order through v_readlane -- the same sum, in the same order, as a thread walking the chunks,
 // without its chain of dependent L2 reads (32 chunks: 9.9 -> ~3 us).
-__device__ __forceinline__ void granule_store(unsigned long long *dst, uint32_t seq, uint32_t value_bits)
-{
-    // ONE aligned 8-byte store carries the value and the tag of the exchange it belongs to: whoever reads the tag it waits
-    // for has the value (no flag, no fence); system scope: the mailbox may be another GPU's memory
-    __hip_atomic_store(dst, ((unsigned long long)value_bits << 32) | (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// waits for the granule of exchange v.seq at `src` (a section of THIS rank's mailbox written by rank `from`): its value bits,
-// or NaN after the time-out / when the word already carries a LATER exchange's tag (the peer gave up on this rank and moved
-// on) -- with rank `from`'s bit set in the error words, as k_allgather_p2p does
-__device__ __forceinline__ uint32_t granule_wait(const unsigned long long *src, const P2pGranuleView &v, int from)
-{
-    const unsigned long long t0 = real_time();
-    unsigned long long limit = v.timeout_ticks;
-    bool known_late = false;
-    for (;;) {
-        const unsigned long long g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const uint32_t tag = (uint32_t)g;
-        if (tag == v.seq) return (uint32_t)(g >> 32);
-        if (!known_late) {                                            // (read once, on the slow path only)
-            known_late = true;
-            const uint32_t seen = __hip_atomic_load(v.err_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (((seen >> (from & 31)) & 1u) && limit > 200000ull) limit = 200000ull;      // 2 ms for a peer that was late before
-        }
-        if ((int32_t)(tag - v.seq) > 0 || real_time() - t0 > limit) {
-            atomicOr_system(v.err, 1u << (from & 31));
-            atomicOr(v.err_seen, 1u << (from & 31));
-            return 0x7FC00000u;
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-
 // The update over granules (ses_openai_generation_sharded on the peer-store transport): lane c WAITS for the granule of
 // chunk c -- rank c / cl's section of this rank's mailbox, written by that rank's gradient kernel -- instead of loading a
 // float from an all-gathered array; the ordered sum and Adam are k_es_apply's.  A chunk that does not arrive in time is NaN

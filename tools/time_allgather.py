@@ -15,7 +15,8 @@ rank, world = dist.get_rank(), dist.get_world_size()
 es = HipES("CartPole-v1", 4, 2, True, False, max_step=500, eval_ep_num=5)
 assert attach_comm(es), "no library transport"
 owner = es._comm_owner
-for n in (4096, 8192, 65536 // world):
+for n, gran in ((4096, 1), (4096, 0), (8192, 1), (8192, 0), (65536 // world, 1), (65536 // world, 0)):
+    owner.set_tuning("comm_granule_allgather", gran)        # 1: {exchange number, value} granules; 0: data + sequence words
     local = torch.full((n,), float(rank), device=es.device)
     out = es.empty(world * n)
     for _ in range(20):
@@ -34,7 +35,7 @@ for n in (4096, 8192, 65536 // world):
         dist.barrier()
     ok = bool(torch.equal(out.view(world, n)[:, 0].cpu(), torch.arange(world, dtype=torch.float32)))
     if rank == 0:
-        print(json.dumps({"ranks_on_one_gpu": world, "floats_per_rank": n, "transport": comm_transport(es, n),
+        print(json.dumps({"ranks_on_one_gpu": world, "floats_per_rank": n, "transport": comm_transport(es, n), "granules": bool(gran and n <= 32768),
                           "us_per_exchange": round(statistics.median(ts), 2), "correct": ok}), flush=True)
 es.close()
 dist.destroy_process_group()
