@@ -66,6 +66,19 @@ WORKER = textwrap.dedent("""
             assert torch.equal(thetas[r].view(torch.int32), theta_ref[lo:lo + thetas[r].shape[0]].view(torch.int32)), (gen, r, "theta")
         assert float(best_ref) == 1000.0 + gen
         state = new
+    # the all-gather itself in both forms (sequence words / granules), 5000 floats per rank = two slices of the grid
+    for gran in (0, 1):
+        locals_, outs_ = [], []
+        for r, es in enumerate(ranks):
+            es.set_tuning("comm_granule_allgather", gran)
+            with torch.cuda.stream(streams[r]):
+                loc = torch.arange(5000, device="cuda", dtype=torch.float32) + 10000.0 * r + gran
+                locals_.append(loc)
+                outs_.append(es.allgather_fitness(loc))
+        torch.cuda.synchronize()
+        want = torch.cat(locals_)
+        for r, es in enumerate(ranks):
+            assert es.comm_p2p_status() == 0 and torch.equal(outs_[r], want), (gran, r)
     for es in ranks:
         es.comm_p2p_detach()
     print("ok", world, per, n)
