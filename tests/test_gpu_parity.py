@@ -348,8 +348,10 @@ def test_rollout_wild_initial_states_take_the_general_loop(lpe):
 
 @pytest.mark.parametrize("n", [1638, 1639, 1640, 2049, 9830, 9831])
 def test_rollout_split_boundaries(n):
-    """Population sizes on both sides of the launch heuristics (pure LPE-8 below 8192 episodes, the mixed LPE-8 + LPE-4
-    split up to 49 152, pure LPE-4 above): the ragged last waves of each part must still land on the oracle's bits."""
+    """Population sizes on both sides of the boundaries of the split chooser (csrc/ses_rollout.hip, choose_cartpole_mlp_split:
+    up to 8192 episodes one of the pure splits -- 16, 8 or 4 lanes per env, by the issue-cost model --, from there to 49 152 also
+    "one light wave per SIMD at 16 or 8 lanes per env + the rest at 4", pure 4 lanes per env above): the ragged last waves of
+    each part must still land on the oracle's bits."""
     from ses import HipES
     rng = np.random.RandomState(n)
     theta = (rng.randn(n, 226) * 0.6).astype(np.float32)
