@@ -107,7 +107,8 @@ int ses_sync(ses_handle *h);
  * "comm_granule_allgather" (default 0; 1: ses_allgather_fitness over the peer-store transport moves 8-byte {exchange number,
  * value} granules -- the data is its own flag -- while the shard fits half a mailbox section.  Measured slower for a whole
  * fitness shard, 12.4 us against 6.3 at 4096 floats; it is how a rank that does nothing else answers the granule exchange of
- * ses_openai_generation_sharded, tools/time_tail.py).
+ * ses_openai_generation_sharded, tools/time_tail.py), "comm_granules_enabled" (default 1; 0: the handle's transport refuses
+ * granule exchanges, the shard form of the tail then all-gathers its partials as floats).
  * The library itself reads no environment variable. */
 int ses_set_tuning(ses_handle *h, const char *name, int32_t value);
 /* Timing without events: from now on the last kernel of every ses_rollout (the episode mean: end of the rollout phase)
@@ -416,6 +417,10 @@ int ses_comm_p2p_attach(ses_handle *h, const void *handles);
 int ses_comm_p2p_attach_local(ses_handle *h, ses_handle *const *peers);
 int ses_comm_p2p_info(ses_handle *h, int32_t *world, int32_t *max_per_rank, int32_t *exchanges);
 int ses_comm_p2p_status(ses_handle *h, uint32_t *timed_out_mask);   /* bit r: an exchange gave up waiting for rank r */
+/* Clears the time-out mask (drains the handle's stream first): for a host that has dealt with a failed exchange and whose ranks
+ * have AGREED to go on using this transport -- e.g. after a failed check of the granule exchanges at attach time, which switches
+ * those off ("comm_granules_enabled" = 0) and keeps the flag-based exchanges. */
+int ses_comm_p2p_reset_status(ses_handle *h);
 int ses_comm_p2p_detach(ses_handle *h);
 
 #ifdef __cplusplus

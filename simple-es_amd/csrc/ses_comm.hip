@@ -217,7 +217,8 @@ int comm_p2p_granules_begin(ses_handle *comm, int granules, P2pGranuleView *v)
 {
     static_assert(P2P_GRANULE_MAX_WORLD == P2P_MAX_WORLD, "world limit");
     ses_p2p *p = comm ? comm->p2p : nullptr;
-    if (!p || !p->attached || granules < 1 || granules > p->max_per_rank / 2 || (comm->tune_comm_force_rccl && comm->comm))
+    if (!p || !p->attached || granules < 1 || granules > p->max_per_rank / 2 || (comm->tune_comm_force_rccl && comm->comm) ||
+        !comm->tune_comm_granules_enabled)
         return set_error(SES_ERR_UNSUPPORTED, "granule exchange: no peer-store transport for %d granules per rank", granules);
     if (*(volatile uint32_t *)p->err_host != 0u && !comm->tune_comm_p2p_keep_going)
         return set_error(SES_ERR_COMM, "peer-store exchange: an earlier exchange timed out waiting for rank mask 0x%x (its output was "
@@ -415,6 +416,18 @@ int ses_comm_p2p_status(ses_handle *h, uint32_t *timed_out_mask)
 {
     SES_REQUIRE(h && timed_out_mask, "ses_comm_p2p_status: null argument");
     *timed_out_mask = (h->p2p && h->p2p->err_host) ? *(volatile uint32_t *)h->p2p->err_host : 0u;
+    return SES_OK;
+}
+
+int ses_comm_p2p_reset_status(ses_handle *h)
+{
+    SES_REQUIRE(h, "ses_comm_p2p_reset_status: null handle");
+    if (h->p2p && h->p2p->err_host) {
+        SES_HIP_TRY(hipSetDevice(h->cfg.device));
+        SES_HIP_TRY(hipStreamSynchronize(h->stream));                // no exchange of this handle is in flight
+        *(volatile uint32_t *)h->p2p->err_host = 0u;
+        SES_HIP_TRY(hipMemset(h->p2p->err_seen, 0, sizeof(uint32_t)));
+    }
     return SES_OK;
 }
 

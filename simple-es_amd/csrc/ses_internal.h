@@ -54,6 +54,8 @@ struct ses_handle {
     int tune_lander_per_wave;      // offspring per wave of the lockstep lander rollout: 0 = by population size, 1 / 2 / 4
     int tune_comm_p2p_timeout_ms;  // how long a peer-store exchange waits for a peer (0 = the default, 60 s)
     int tune_comm_p2p_keep_going;  // 1: exchanges continue after a time-out (the host polls ses_comm_p2p_status and recovers)
+    int tune_comm_granules_enabled; // 0: this handle's transport refuses granule exchanges (comm_p2p_granules_begin: unsupported) -- set by a host
+                                    // whose check of them failed (ses/parallel.py); the flag-based exchanges carry everything then
     int tune_comm_granules;        // 1: ses_allgather_fitness over the peer-store transport moves {sequence, value} granules (no flag, no fence)
                                    // while a shard fits half a mailbox section; 0 (default): the kernel with sequence words -- for a whole
                                    // shard the per-float stores and polls cost more than the one release / acquire round they save

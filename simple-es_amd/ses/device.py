@@ -230,6 +230,10 @@ class HipES:
         check(self._lib.ses_comm_p2p_status(self._h, ctypes.byref(m)), "ses_comm_p2p_status")
         return m.value
 
+    def comm_p2p_reset_status(self):
+        """ses_comm_p2p_reset_status: clear the time-out mask (the ranks have agreed to keep using the transport)."""
+        check(self._lib.ses_comm_p2p_reset_status(self._h), "ses_comm_p2p_reset_status")
+
     def comm_p2p_detach(self):
         check(self._lib.ses_comm_p2p_detach(self._h), "ses_comm_p2p_detach")
         self._route = None

@@ -77,6 +77,33 @@ def _attach_p2p(owner, rank, world, group):
             ok = False
             print(f"[ses] rank {rank}: peer-store self-test failed ({exc})", file=sys.stderr, flush=True)
         ok = _cpu_group_ok(ok, owner.device, group)
+    if ok:
+        # The granule exchanges (8-byte {exchange number, value} stores that are their own flag: the chunk partials of the shard
+        # form of the openai_es tail) are checked separately, with a short time-out: if they fail on ANY rank they are switched
+        # off on every rank -- the flag-based exchanges, which have just been checked, then carry the partials too.
+        good = True
+        try:
+            owner.set_tuning("comm_granule_allgather", 1)
+            owner.set_tuning("comm_p2p_timeout_ms", 5000)
+            n = 1031
+            mine = torch.arange(n, device=owner.device, dtype=torch.float32) * 0.5 - 7.0 * (rank + 1)
+            got = owner.allgather_fitness(mine).cpu()
+            owner.sync()
+            want = torch.cat([torch.arange(n, dtype=torch.float32) * 0.5 - 7.0 * (r + 1) for r in range(world)])
+            good = bool(torch.equal(got, want)) and owner.comm_p2p_status() == 0
+        except Exception as exc:
+            good = False
+            print(f"[ses] rank {rank}: granule exchange self-test failed ({exc})", file=sys.stderr, flush=True)
+        finally:
+            owner.set_tuning("comm_granule_allgather", 0)
+            owner.set_tuning("comm_p2p_timeout_ms", int(os.environ.get("SES_COMM_P2P_TIMEOUT_MS", "0")))
+        good = _cpu_group_ok(good, owner.device, group)
+        if not good:
+            print(f"[ses] rank {rank}: granule exchanges switched off on this transport (flag-based exchanges carry everything)",
+                  file=sys.stderr, flush=True)
+            owner.set_tuning("comm_granules_enabled", 0)
+            owner.comm_p2p_reset_status()
+            dist.barrier(group=group)
     if not ok:
         try:
             owner.comm_p2p_detach()
