@@ -108,7 +108,10 @@ int ses_sync(ses_handle *h);
  * value} granules -- the data is its own flag -- while the shard fits half a mailbox section.  Measured slower for a whole
  * fitness shard, 12.4 us against 6.3 at 4096 floats; it is how a rank that does nothing else answers the granule exchange of
  * ses_openai_generation_sharded, tools/time_tail.py), "comm_granules_enabled" (default 1; 0: the handle's transport refuses
- * granule exchanges, the shard form of the tail then all-gathers its partials as floats).
+ * granule exchanges, the shard form of the tail then all-gathers its partials as floats), "fused_fitness_exchange" (default 1:
+ * inside a sharded ses_run_generations above 8192 rows the fitness exchange needs no launch either -- the episode-mean kernel
+ * stores every value as a granule into every rank's mailbox, the rank kernel polls the tiles it sorts; 0: ses_allgather_fitness
+ * between rollout and tail).
  * The library itself reads no environment variable. */
 int ses_set_tuning(ses_handle *h, const char *name, int32_t value);
 /* Timing without events: from now on the last kernel of every ses_rollout (the episode mean: end of the rollout phase)
@@ -416,6 +419,9 @@ int ses_comm_p2p_attach(ses_handle *h, const void *handles);
  * every handle must detach before any of them is destroyed. */
 int ses_comm_p2p_attach_local(ses_handle *h, ses_handle *const *peers);
 int ses_comm_p2p_info(ses_handle *h, int32_t *world, int32_t *max_per_rank, int32_t *exchanges);
+/* exchanges issued over the attached transport so far, by kind: with sequence words (ses_allgather_fitness) / as granules (the
+ * exchanges kernels do themselves: chunk partials and, inside ses_run_generations, the fitness; the granule all-gather) */
+int ses_comm_p2p_counts(ses_handle *h, int32_t *flag_exchanges, int32_t *granule_exchanges);
 int ses_comm_p2p_status(ses_handle *h, uint32_t *timed_out_mask);   /* bit r: an exchange gave up waiting for rank r */
 /* Clears the time-out mask (drains the handle's stream first): for a host that has dealt with a failed exchange and whose ranks
  * have AGREED to go on using this transport -- e.g. after a failed check of the granule exchanges at attach time, which switches

@@ -412,6 +412,15 @@ int ses_comm_p2p_info(ses_handle *h, int32_t *world, int32_t *max_per_rank, int3
     return SES_OK;
 }
 
+int ses_comm_p2p_counts(ses_handle *h, int32_t *flag_exchanges, int32_t *granule_exchanges)
+{
+    SES_REQUIRE(h, "ses_comm_p2p_counts: null handle");
+    const bool on = h->p2p && h->p2p->attached;
+    if (flag_exchanges) *flag_exchanges = on ? (int32_t)h->p2p->seq : 0;
+    if (granule_exchanges) *granule_exchanges = on ? (int32_t)h->p2p->gseq : 0;
+    return SES_OK;
+}
+
 int ses_comm_p2p_status(ses_handle *h, uint32_t *timed_out_mask)
 {
     SES_REQUIRE(h && timed_out_mask, "ses_comm_p2p_status: null argument");

@@ -51,6 +51,9 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
     const int n_loc = multi ? st->n_local : n;                         // rows of theta / init on this rank
     const int64_t first = multi ? st->first_row : 0;
     const bool sharded_tail = multi && openai && ses_openai_sharded_ok(h, st->comm, n, st->per_rank, st->world) == 1;
+    // ... and then the fitness exchange itself needs no launch: the episode-mean kernel stores every value as a granule into every
+    // rank's mailbox, the rank kernel of the tail polls the tiles it sorts (k_fitness_mean_granules, k_rank_sort_search<true>)
+    const bool fused_fit = sharded_tail && openai_fused_fitness_ok(h, n, st->per_rank) == 1;
     int rc = SES_OK;
     // The env resets depend on (env seed, generation key) only: those of all k generations are drawn up front in ONE launch
     // (keyed like ESLoop._init_states), into a buffer the handle owns -- a 4 us kernel per generation less on the
@@ -80,11 +83,19 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
             if (rc != SES_OK) break;
         }
         h->stamp = stamps ? (unsigned long long *)(stamps + 2 * g) : nullptr;          // end of the rollout phase
+        P2pGranuleView fit_view;
+        bool fused = false;
+        if (fused_fit) {
+            const int grc = comm_p2p_granules_begin(st->comm, st->per_rank, &fit_view);
+            if (grc == SES_ERR_COMM) { rc = grc; break; }
+            fused = grc == SES_OK;                                                      // (unsupported: RCCL only, or granules switched off)
+            if (fused) { h->fit_gv = &fit_view; h->fit_own = st->fit_local; }
+        }
         if (n_loc > 0)
             rc = ses_rollout(h, st->theta[cur], init, st->shared_init ? 0 : 1, n_loc, st->mode, multi ? st->fit_local : st->fitness,
                              nullptr, nullptr);
-        if (rc != SES_OK) break;
-        if (multi) {
+        if (rc != SES_OK) { h->fit_gv = nullptr; break; }
+        if (multi && !fused) {
             // loop.py:66-79, the gather half of Pool.map: fitness[r * per_rank + i] = rank r's fit_local[i] (a ragged last
             // shard ends in the -inf the caller put there once)
             rc = ses_allgather_fitness(st->comm, st->fit_local, st->per_rank, st->fitness);
@@ -109,6 +120,8 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
                                            st->adam_m[cur], st->adam_v[cur], st->parents[nxt], st->adam_m[nxt], st->adam_v[nxt],
                                            (float)st->sigma, st->pop_gen + 1, n_loc > 0 ? first : 0, n_loc, st->theta[nxt], best + g);
             st->pop_sigma = st->sigma;
+            h->fit_gv = nullptr;
+            h->fit_own = nullptr;
         } else {
             int32_t *rank = st->work_i32, *ids = rank + n, *pidx = ids + ke, *alias = pidx + ke;
             const bool evo = st->strategy == SES_STRATEGY_SIMPLE_EVOLUTION;

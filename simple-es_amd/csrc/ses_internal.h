@@ -7,6 +7,7 @@
 
 #include "../../include/ses.h"
 
+namespace ses { struct P2pGranuleView; }
 struct ses_handle {
     ses_config cfg;
     hipStream_t stream;
@@ -46,6 +47,11 @@ struct ses_handle {
     int tune_env_step_lds;         // bytes of LDS each of its workgroups reserves without touching them: limits the waves in flight;
                                    // -1 (default): derived from the device's LDS per CU and tune_env_step_waves
     int tune_env_step_waves;       // waves per CU the derived reservation keeps in flight (7: what the memory system wants)
+    // Transient, set by ses_run_generations around the calls of one generation (null otherwise): the granule view of a fitness
+    // exchange that the episode-mean kernel feeds (every rank's mailbox gets this rank's fitness values as granules) and the
+    // shard form of the tail consumes (k_rank_sort_search polls the tiles it sorts); fit_own: this rank's own fitness values.
+    const ses::P2pGranuleView *fit_gv;
+    const float *fit_own;
     int lds_per_cu;                // hipDeviceAttributeMaxSharedMemoryPerMultiprocessor of the handle's device
     int env_step_key[3];           // (block, lds knob, waves knob) the two values below were resolved for
     int env_step_lds_resolved;     // the reservation actually launched with
@@ -54,6 +60,7 @@ struct ses_handle {
     int tune_lander_per_wave;      // offspring per wave of the lockstep lander rollout: 0 = by population size, 1 / 2 / 4
     int tune_comm_p2p_timeout_ms;  // how long a peer-store exchange waits for a peer (0 = the default, 60 s)
     int tune_comm_p2p_keep_going;  // 1: exchanges continue after a time-out (the host polls ses_comm_p2p_status and recovers)
+    int tune_fused_fitness;        // 1 (default): in a sharded ses_run_generations the FITNESS exchange needs no launch either (see fit_gv below)
     int tune_comm_granules_enabled; // 0: this handle's transport refuses granule exchanges (comm_p2p_granules_begin: unsupported) -- set by a host
                                     // whose check of them failed (ses/parallel.py); the flag-based exchanges carry everything then
     int tune_comm_granules;        // 1: ses_allgather_fitness over the peer-store transport moves {sequence, value} granules (no flag, no fence)
@@ -139,6 +146,8 @@ __device__ __forceinline__ uint32_t granule_wait(const unsigned long long *src, 
 }
 
 #endif
+
+int openai_fused_fitness_ok(const ses_handle *h, int32_t n, int32_t per_rank);     // ses_strategy.hip
 
 int ensure_episode_scratch(ses_handle *h, size_t episodes);
 int ensure_reduce_scratch(ses_handle *h, size_t bytes);

@@ -894,6 +894,23 @@ __global__ void k_fitness_mean(const double *__restrict__ ep_return, int n_rows,
     fitness[i] = (float)(total / (double)E);
 }
 
+// The same mean, and the fitness exchange of a sharded run in the same launch (ses_run_generations, "fused_fitness_exchange"):
+// every thread also stores its value as an 8-byte {exchange number, value} granule into the mailbox of EVERY rank (its own
+// included) -- one store per rank, the data is its own flag -- where the ranks' rank kernels poll the tiles they sort
+// (k_rank_sort_search).  No exchange launch between the rollout and the tail.
+__global__ void k_fitness_mean_granules(const double *__restrict__ ep_return, int n_rows, int E, float *__restrict__ fitness,
+                                        unsigned long long *__restrict__ stamp, P2pGranuleView gv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (stamp && i == 0) *stamp = real_time();
+    if (i >= n_rows) return;
+    double total = 0.0;
+    for (int e = 0; e < E; ++e) total += ep_return[(size_t)i * E + e];
+    const float f = (float)(total / (double)E);
+    fitness[i] = f;
+    for (int r = 0; r < gv.world; ++r) granule_store(gv.dst[r] + i, gv.seq, f2u(f));
+}
+
 // ------------------------------------------------------------------------------------------------
 // Standalone SoA env step: pure streaming, 16 B per lane per array (7 loads + 6 stores = 52 B/env).
 template <bool FIXED_LENGTH>
@@ -1438,8 +1455,12 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
     } else {
         launch_cartpole_mlp(h, theta, init, init_per_offspring, n_rows, mode, epr, ep_steps);
     }
-    hipLaunchKernelGGL(k_fitness_mean, dim3(ceil_div(n_rows, 256)), dim3(256), 0, h->stream, epr, n_rows,
-                       h->cfg.eval_ep_num, fitness, h->stamp);
+    if (h->fit_gv)
+        hipLaunchKernelGGL(k_fitness_mean_granules, dim3(ceil_div(n_rows, 256)), dim3(256), 0, h->stream, epr, n_rows,
+                           h->cfg.eval_ep_num, fitness, h->stamp, *h->fit_gv);
+    else
+        hipLaunchKernelGGL(k_fitness_mean, dim3(ceil_div(n_rows, 256)), dim3(256), 0, h->stream, epr, n_rows,
+                           h->cfg.eval_ep_num, fitness, h->stamp);
     SES_HIP_TRY(hipGetLastError());
     return SES_OK;
 }

@@ -258,14 +258,27 @@ __global__ __launch_bounds__(256) void k_rank_search(const float *__restrict__ f
 // A shard's own rows against ALL tiles in one launch (ses_openai_generation_sharded): workgroup (x, y) sorts tile y
 // itself -- the sort is repeated by the n_own / 1024 workgroups that share the tile, a few microseconds of otherwise idle
 // CUs instead of a dependent launch -- and then searches it for its 1024 own rows, two per thread.
+// GRAN: there is no gathered fitness vector.  The tile's values are polled as granules in this rank's mailbox, where the
+// episode-mean kernel of the rank that owns the tile's rows has stored them (k_fitness_mean_granules; per_rank is a multiple
+// of the tile, so a tile has one owner); `fit` then holds this rank's OWN values only, indexed from `first`.
+template <bool GRAN>
 __global__ __launch_bounds__(RANK_TILE / 2) void k_rank_sort_search(const float *__restrict__ fit, int n, int first,
-                                                                    int n_own, int32_t *__restrict__ rank_own)
+                                                                    int n_own, int32_t *__restrict__ rank_own,
+                                                                    P2pGranuleView gv = P2pGranuleView{}, int per_rank = 1)
 {
     __shared__ unsigned long long buf[2][RANK_TILE];
     const int base = blockIdx.y * RANK_TILE;
     const int a = (threadIdx.x >> 6) * 128 + (threadIdx.x & 63), b = a + 64;
-    unsigned long long xa = base + a < n ? rank_key(f2u(fit[base + a]), (uint32_t)(base + a)) : 0ull;
-    unsigned long long xb = base + b < n ? rank_key(f2u(fit[base + b]), (uint32_t)(base + b)) : 0ull;
+    unsigned long long xa = 0ull, xb = 0ull;
+    if (GRAN) {
+        const int owner = base / per_rank;
+        const unsigned long long *src = gv.src + (size_t)owner * gv.section + (base - owner * per_rank);
+        if (base + a < n) xa = rank_key(granule_wait(src + a, gv, owner), (uint32_t)(base + a));
+        if (base + b < n) xb = rank_key(granule_wait(src + b, gv, owner), (uint32_t)(base + b));
+    } else {
+        xa = base + a < n ? rank_key(f2u(fit[base + a]), (uint32_t)(base + a)) : 0ull;
+        xb = base + b < n ? rank_key(f2u(fit[base + b]), (uint32_t)(base + b)) : 0ull;
+    }
     bitonic_sort_tile(xa, xb, buf);
     // the sort's sixth and last LDS stage used buf[1]; every thread has passed its barrier, so the fifth stage's reads of
     // buf[0] are over and buf[0] can take the sorted tile without another barrier
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(RANK_TILE / 2) void k_rank_sort_search(const float 
         const int il = blockIdx.x * RANK_TILE + half * (RANK_TILE / 2) + threadIdx.x;
         if (il >= n_own) continue;
         const int i = first + il;
-        const unsigned long long ki = rank_key(f2u(fit[i]), (uint32_t)i);
+        const unsigned long long ki = rank_key(f2u(fit[GRAN ? il : i]), (uint32_t)i);
         int lo = 0, hi = RANK_TILE;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
@@ -649,6 +662,18 @@ __global__ void k_gather_rows(const float *__restrict__ src, const int32_t *__re
 
 }  // namespace ses
 
+// ses_run_generations: may the fitness exchange of this layout be fused into the episode-mean kernel (producer) and
+// k_rank_sort_search (consumer)?  Needs the sort path of the shard form, and a consumer grid that stays a fraction of the chip:
+// its workgroups spin until the peers' values are there, and ranks that SHARE a GPU (the test rigs) must leave room for the
+// rollouts they wait for.
+namespace ses {
+int openai_fused_fitness_ok(const ses_handle *h, int32_t n, int32_t per_rank)
+{
+    if (!h->tune_fused_fitness || n <= RANK_SORT_MIN || per_rank % RANK_TILE != 0) return 0;
+    return (long long)ceil_div(per_rank, RANK_TILE) * ceil_div(n, RANK_TILE) <= 512 ? 1 : 0;
+}
+}  // namespace ses
+
 extern "C" {
 
 using namespace ses;
@@ -804,6 +829,10 @@ static int openai_generation_impl(ses_handle *h, ses_handle *comm, const float *
     const int chunks = ceil_div(n, ES_CHUNK);
     const bool sharded = comm != nullptr;
     const bool count_rank = n <= RANK_SORT_MIN;                        // counting rank, keys formed inside the count
+    // ses_run_generations with the fitness exchange fused into its producer and consumer: no gathered vector exists, the
+    // own values are at h->fit_own and every use of fitness[i] below is for an own row
+    const bool fused_fit = comm != nullptr && h->fit_gv != nullptr && !count_rank;
+    if (fused_fit) fitness = h->fit_own - first_row;
     const int n_own = sharded ? n_rows : n;                            // rows this rank ranks and accumulates
     const int first = sharded ? (int)first_row : 0;
     const int cl = sharded ? per_rank / ES_CHUNK : chunks;             // chunks per rank's payload
@@ -832,8 +861,11 @@ static int openai_generation_impl(ses_handle *h, ses_handle *comm, const float *
         if (count_rank) {
             hipLaunchKernelGGL(k_rank_count_fitness, dim3(ceil_div(n_own, 256), ceil_div(n, jt)), dim3(256), 0, h->stream, fitness,
                                n, (int)jt, first, n_own, rank);
+        } else if (sharded && fused_fit) {
+            hipLaunchKernelGGL((k_rank_sort_search<true>), dim3(ceil_div(n_own, RANK_TILE), tiles), dim3(RANK_TILE / 2), 0, h->stream,
+                               h->fit_own, n, first, n_own, rank, *h->fit_gv, per_rank);
         } else if (sharded) {
-            hipLaunchKernelGGL(k_rank_sort_search, dim3(ceil_div(n_own, RANK_TILE), tiles), dim3(RANK_TILE / 2), 0, h->stream,
+            hipLaunchKernelGGL((k_rank_sort_search<false>), dim3(ceil_div(n_own, RANK_TILE), tiles), dim3(RANK_TILE / 2), 0, h->stream,
                                fitness, n, first, n_own, rank);
         } else {
             hipLaunchKernelGGL(k_rank_tile_sort, dim3(tiles), dim3(RANK_TILE / 2), 0, h->stream, fitness, n, sorted);

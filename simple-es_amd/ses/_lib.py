@@ -114,6 +114,7 @@ SIGNATURES = {
     "ses_comm_p2p_attach": [_vp, _vp],
     "ses_comm_p2p_attach_local": [_vp, _vp],
     "ses_comm_p2p_info": [_vp, _vp, _vp, _vp],
+    "ses_comm_p2p_counts": [_vp, _vp, _vp],
     "ses_comm_p2p_status": [_vp, _vp],
     "ses_comm_p2p_reset_status": [_vp],
     "ses_comm_p2p_detach": [_vp],

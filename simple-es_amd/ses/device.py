@@ -223,6 +223,12 @@ class HipES:
         check(self._lib.ses_comm_p2p_info(self._h, ctypes.byref(w), ctypes.byref(m), ctypes.byref(x)), "ses_comm_p2p_info")
         return w.value, m.value, x.value
 
+    def comm_p2p_counts(self):
+        """(exchanges with sequence words, granule exchanges) issued over the attached peer-store transport so far."""
+        f, g = ctypes.c_int32(), ctypes.c_int32()
+        check(self._lib.ses_comm_p2p_counts(self._h, ctypes.byref(f), ctypes.byref(g)), "ses_comm_p2p_counts")
+        return f.value, g.value
+
     def comm_p2p_status(self):
         """Bit mask of the ranks some peer-store exchange of this handle gave up waiting for (0 = all good).  Reads a
         host-visible word: no stream operation, no synchronisation."""

@@ -229,6 +229,8 @@ SHARDED_WORKER = textwrap.dedent("""
                "strategy": {"name": "openai_es", "init_sigma": 0.5, "sigma_decay": 0.99, "learning_rate": 0.05,
                             "offspring_num": n, "seed": 5}}
         loop = builder.build_loop(cfg, 5, 1, 2, False, 10 ** 9)
+        owner0 = getattr(loop.dev, "_comm_owner", None)
+        counts0 = owner0.comm_p2p_counts() if owner0 is not None else (0, 0)
         fits = []
         if not batched:                      # observing the rollouts keeps run() on the per-generation path
             orig = loop.rollout
@@ -243,7 +245,8 @@ SHARDED_WORKER = textwrap.dedent("""
         np.savez(os.path.join(out_dir, f"sh_{n}_w{world}_r{rank}.npz"), fits=np.stack(fits) if fits else np.zeros(0),
                  elite=strat.get_elite_model().flat(), best=np.array([b for b, _ in loop.history]),
                  m=strat.optimizer.m.cpu().numpy(), v=strat.optimizer.v.cpu().numpy(), theta=pop.theta.cpu().numpy(),
-                 first=pop.shard.first, sharded=sharded, batched_generations=loop.batched_generations)
+                 first=pop.shard.first, sharded=sharded, batched_generations=loop.batched_generations,
+                 exchanges=np.array(owner0.comm_p2p_counts() if owner0 is not None else (0, 0)) - np.array(counts0))
     if world > 1:
         dist.destroy_process_group()
 """)
@@ -258,19 +261,25 @@ def _run_ranks(script, tmp_path, world, extra, env=None, timeout=900):
     return run
 
 
-@pytest.mark.parametrize("world,sizes,mode", [(2, "2048,10239", "stepwise"), (4, "4096,12285", "stepwise"),
-                                              (2, "2048,10239", "batched"), (4, "12285", "batched")],
-                         ids=["2_ranks", "4_ranks", "2_ranks_device_loop", "4_ranks_device_loop"])
-def test_sharded_openai_tail_equals_one_rank_bitwise(tmp_path, world, sizes, mode):
+@pytest.mark.parametrize("world,sizes,mode,tuning",
+                         [(2, "2048,10239", "stepwise", ""), (4, "4096,12285", "stepwise", ""), (2, "2048,10239", "batched", ""),
+                          (4, "12285", "batched", ""), (2, "10239", "batched", "fused_fitness_exchange=0"),
+                          (2, "10239", "batched", "openai_granule_exchange=0")],
+                         ids=["2_ranks", "4_ranks", "2_ranks_device_loop", "4_ranks_device_loop", "2_ranks_device_loop_fitness_allgather",
+                              "2_ranks_device_loop_partials_allgather"])
+def test_sharded_openai_tail_equals_one_rank_bitwise(tmp_path, world, sizes, mode, tuning):
     """Shards aligned to the gradient's 1024-row chunks: every rank ranks and accumulates its own rows only, the chunk
     partials (and the best-reward candidates) are all-gathered through the mailboxes, the ordered update finishes --
     fitness vectors, best rewards, parent, Adam moments and the next population's rows equal the one-rank run bit for bit.
     2048 rows: counting rank; 10 239 / 12 285: one sort + search launch, last shard ragged (5119 of 5120, 3069 of 3072
-    rows).  `device_loop`: the same through ESLoop.run()'s ses_run_generations path, all-gather inside the C loop."""
+    rows).  `device_loop`: the same through ESLoop.run()'s ses_run_generations path -- above 8192 rows with BOTH exchanges of a
+    generation fused into the kernels around them (the episode-mean kernel stores the fitness granules, the rank kernel polls
+    them; the gradient kernel stores the partials, the update polls them); the last two cases switch one of the two back to an
+    all-gather launch of its own."""
     script = tmp_path / "sh.py"
     script.write_text(SHARDED_WORKER % (ROOT, SRC))
     _run_ranks(script, tmp_path, 1, [sizes, mode])
-    _run_ranks(script, tmp_path, world, [sizes, mode])
+    _run_ranks(script, tmp_path, world, [sizes, mode], env={"SES_TUNING": tuning} if tuning else None)
     for n in (int(x) for x in sizes.split(",")):
         ref = np.load(tmp_path / f"sh_{n}_w1_r0.npz")
         assert len(ref["best"]) == 5 and np.isfinite(ref["best"]).all()
@@ -283,6 +292,10 @@ def test_sharded_openai_tail_equals_one_rank_bitwise(tmp_path, world, sizes, mod
             lo = int(got["first"])
             assert np.array_equal(got["theta"].view(np.uint32), ref["theta"][lo:lo + got["theta"].shape[0]].view(np.uint32)), (n, r)
             assert int(got["batched_generations"]) == (5 if mode == "batched" else 0)
+            # what carried the two exchanges of the 5 generations: (launches of ses_allgather_fitness, granule exchanges)
+            want = {("stepwise", ""): (5, 5), ("batched", "fused_fitness_exchange=0"): (5, 5), ("batched", "openai_granule_exchange=0"): (5, 5),
+                    ("batched", ""): (5, 5) if n <= 8192 else (0, 10)}[(mode, tuning)]
+            assert tuple(int(v) for v in got["exchanges"]) == want, (n, r, mode, tuning, got["exchanges"])
         assert int(ref["batched_generations"]) == (5 if mode == "batched" else 0)
 
 
