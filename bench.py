@@ -304,6 +304,12 @@ class Job:
         return {"rollout_us": med[0], "allgather_us": med[1], "fitness_loop_us": med[2]}
 
 
+def exchange_counts(job):
+    """(all-gather launches, granule exchanges) issued over the peer-store transport so far (ses_comm_p2p_counts), or None."""
+    owner = getattr(job.loop.dev, "_comm_owner", None)
+    return owner.comm_p2p_counts() if owner is not None and owner.comm_route()[0] else None
+
+
 def timed_blocks(job, steps, blocks, barrier, dist, world):
     """`blocks` times: EXACTLY `steps` generations between barrier + synchronize on both sides, MAX over ranks."""
     out = []
@@ -380,8 +386,15 @@ def run_rank(args):
     job.generations(preroll)                                   # clock ramp; a generation is ~0.25 ms
     job.reset()                                                # the measured run starts from the zero network
     job.generations(args.warmup)
+    c0 = exchange_counts(job)
     times = timed_blocks(job, args.steps, max(args.blocks, 1), barrier, dist, world)
+    c1 = exchange_counts(job)
     weak = summarise(job, args.steps, times)
+    if c0 is not None and c1 is not None:
+        # what carried the two exchanges of a generation during the timed blocks: launches of ses_allgather_fitness / exchanges the
+        # kernels did themselves with granules (the fitness inside ses_run_generations above 8192 rows, the chunk partials)
+        gens = args.steps * max(args.blocks, 1)
+        weak["exchanges_per_generation"] = {"allgather_launches": (c1[0] - c0[0]) / gens, "granule_exchanges": (c1[1] - c0[1]) / gens}
     from ses.parallel import comm_info, comm_transport
     comm_rank, comm_world, rccl_version = comm_info(job.loop.dev)
     transport = comm_transport(job.loop.dev, -(-job.n_global // world)) if world > 1 else "none"
@@ -425,8 +438,13 @@ def run_rank(args):
                 j = Job(args, n_total, world)
                 j.reset()
                 j.generations(30)
+                c0 = exchange_counts(j)
                 t = timed_blocks(j, x_steps, x_blocks, barrier, dist, world)
+                c1 = exchange_counts(j)
                 rec = summarise(j, x_steps, t)
+                if c0 is not None and c1 is not None:
+                    rec["exchanges_per_generation"] = {"allgather_launches": (c1[0] - c0[0]) / (x_steps * x_blocks),
+                                                       "granule_exchanges": (c1[1] - c0[1]) / (x_steps * x_blocks)}
                 rec.update(j.phases())
                 rec["rccl_ranks"] = comm_info(j.loop.dev)[1]
                 rec["allgather_transport"] = comm_transport(j.loop.dev, -(-n_total // world)) if world > 1 else "none"
