@@ -49,12 +49,10 @@ SES_OUT=$R/ab/libT.so SES_OBJ=/tmp/objT bash simple-es_amd/csrc/build.sh -DSES_P
 for w in walker lander c3; do SES_LIB_PATH=$R/ab/libT.so python tools/walker_phases.py $w 4096 2>/dev/null; done > $OUT/${TAG}_step_phases.txt
 python tools/c3_breakdown.py > $OUT/${TAG}_c3_breakdown.txt 2>&1
 python tools/lander_step_cost.py > $OUT/${TAG}_lander_step_cost.txt 2>&1
-SES_TAIL_SHAPES=1x4096,2x4096,4x4096,4x8192,4x16384 python tools/time_tail.py > $OUT/${TAG}_time_tail.txt 2>&1
-# the shard form of the tail by kernel at the 8-rank shapes: eight in-process ranks oversubscribe the hardware queues of one GPU
-# (the loop as a whole then runs at the queue scheduler's pace), but a kernel's own duration in the trace does not depend on that
-rm -rf gpurun_out/prof_tail
-(cd /tmp && export TMPDIR=/tmp && SES_TAIL_SHAPES=8x4096,8x8192 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_tail -- python3 $R/tools/time_tail.py > $R/gpurun_out/prof_tail.txt 2>&1)
-python tools/tail_by_kernel.py $(find gpurun_out/prof_tail -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_tail_by_kernel.txt 2>&1; cat $OUT/${TAG}_tail_by_kernel.txt
+# the multi-rank side (tests excluded: they ran above): exchange latency by kind, a generation of two ranks with and without the
+# fused exchanges, the openai_es tail replicated / in shard form, the 8-rank shapes by kernel
+bash tools/gpu_multirank_round.sh notests > $OUT/multirank_round.txt 2>&1
+for f in time_allgather time_multirank_generation time_tail_sharded tail_by_kernel; do cp gpurun_out/${TAG}_$f.txt $OUT/ 2>/dev/null; done
 # bench.py --gpus 2 / 4 rehearsed with the ranks sharing this GPU (gloo control plane, peer-store transport): the multi-rank
 # code path of the bench, NOT a scaling measurement
 for n in 2 4; do

@@ -1,9 +1,12 @@
 #!/bin/bash
-# round 4: granule all-gather -- multi-rank tests, exchange latency A/B, sharded tail timings (peers answering / full)
+# the multi-rank round (one gpurun call): multi-rank tests (skipped with "notests"), exchange latency by kind, a generation of two ranks with
+# and without the fused exchanges, the openai_es tail replicated / in shard form, the 8-rank shapes by kernel from a trace
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_sharded_tail.py tests/test_gpu_multirank.py tests/test_gpu_comm.py -x -q > gpurun_out/pytest_f.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/pytest_f.log
+if [ "$1" != "notests" ]; then
+  timeout -k 10 900 python -m pytest tests/test_gpu_sharded_tail.py tests/test_gpu_multirank.py tests/test_gpu_comm.py -x -q > gpurun_out/pytest_f.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/pytest_f.log
+fi
 for w in 2 4; do
   timeout -k 10 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node $w --master-addr 127.0.0.1 --master-port $((29500 + w)) tools/time_allgather.py 2>/dev/null | grep "^{"
 done | tee gpurun_out/r04_time_allgather.txt
