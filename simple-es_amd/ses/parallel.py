@@ -65,8 +65,9 @@ def _attach_p2p(owner, rank, world, group):
         try:
             # ("comm_p2p_keep_going" stays 0 here: the exchange AFTER a timed-out one fails loudly with SES_ERR_COMM.  Only a
             # caller that owns a recovery -- ESLoop.run() for a guarded run, comm_keep_going below -- switches it on.)
-            if os.environ.get("SES_COMM_P2P_TIMEOUT_MS"):
-                owner.set_tuning("comm_p2p_timeout_ms", int(os.environ["SES_COMM_P2P_TIMEOUT_MS"]))
+            # The two checked exchanges below wait 5 s at most for a peer (not the run's time-out, 60 s by default): every rank is
+            # HERE, a peer that does not answer within seconds will not answer at all.
+            owner.set_tuning("comm_p2p_timeout_ms", 5000)
             n = 257
             mine = torch.arange(n, device=owner.device, dtype=torch.float32) + 1000.0 * (rank + 1)
             got = owner.allgather_fitness(mine).cpu()
@@ -84,7 +85,6 @@ def _attach_p2p(owner, rank, world, group):
         good = True
         try:
             owner.set_tuning("comm_granule_allgather", 1)
-            owner.set_tuning("comm_p2p_timeout_ms", 5000)
             n = 1031
             mine = torch.arange(n, device=owner.device, dtype=torch.float32) * 0.5 - 7.0 * (rank + 1)
             got = owner.allgather_fitness(mine).cpu()
@@ -96,8 +96,8 @@ def _attach_p2p(owner, rank, world, group):
             print(f"[ses] rank {rank}: granule exchange self-test failed ({exc})", file=sys.stderr, flush=True)
         finally:
             owner.set_tuning("comm_granule_allgather", 0)
-            owner.set_tuning("comm_p2p_timeout_ms", int(os.environ.get("SES_COMM_P2P_TIMEOUT_MS", "0")))
         good = _cpu_group_ok(good, owner.device, group)
+        owner.set_tuning("comm_p2p_timeout_ms", int(os.environ.get("SES_COMM_P2P_TIMEOUT_MS", "0")))    # the run's own (0 = 60 s)
         if not good:
             print(f"[ses] rank {rank}: granule exchanges switched off on this transport (flag-based exchanges carry everything)",
                   file=sys.stderr, flush=True)
