@@ -4,7 +4,8 @@ Not part of the test suite (minutes of oracle time); run on a GPU box:  python t
 The oracle is one CPU thread per process: tools/fuzz_round.sh runs several seeds side by side (at most 5 processes may hold
 the GPU next to the shell) and adds the tallies up.  Box2D kinds force every kernel of the lander / walker family through
 ses_set_tuning (lanes per env 1 ... 64, one / two / four offspring per wave, episode-parallel, lockstep, MFMA), `envstep`
-drives the step-wise entries (ses_env_reset / ses_env_step_generic) against the oracle's env objects."""
+drives the step-wise entries (ses_env_reset / ses_env_step_generic) against the oracle's env objects, `sharded_tail` the shard
+form of the openai_es tail on 2 or 3 in-process ranks against the replicated tail."""
 import argparse
 import json
 import os
@@ -27,6 +28,60 @@ def dev(a):
 def bits(a):
     a = np.ascontiguousarray(a)
     return a.view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+def sharded_tail_case(rng):
+    """One random layout of the shard form of the openai_es tail (ses_openai_generation_sharded) against the replicated tail:
+    2 or 3 ranks as handles of this process on streams of their own, shards of 1-5 chunks, a ragged last shard, every policy
+    size, both rank paths (counting / sort + search) and both ways the chunk partials travel (granules / float all-gather)."""
+    world = int(rng.choice([2, 3]))
+    per = 1024 * int(rng.choice([1, 1, 2, 3, 4, 5]))
+    n = world * per - int(rng.randint(0, world))
+    S, A, gru = [(4, 2, False), (8, 4, False), (24, 4, False), (12, 5, False), (4, 2, True)][int(rng.randint(0, 5))]
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    ranks = [HipES(None, S, A, A in (2, 5), gru, stream=streams[r]) for r in range(world)]
+    ref = HipES(None, S, A, A in (2, 5), gru)
+    granules = int(rng.randint(0, 2))
+    for r, es in enumerate(ranks):
+        es.set_tuning("comm_p2p_timeout_ms", 20000)
+        es.set_tuning("openai_granule_exchange", granules)
+        es.comm_p2p_export(r, world, 65536)
+    for es in ranks:
+        es.comm_p2p_attach_local(ranks)
+    P = ref.P
+    g = torch.Generator(device="cuda").manual_seed(int(rng.randint(0, 2 ** 31 - 1)))
+    state = [torch.randn(P, device="cuda", generator=g) * 0.1, torch.randn(P, device="cuda", generator=g) * 0.01,
+             torch.rand(P, device="cuda", generator=g) * 0.01]
+    ok = ranks[0].openai_sharded_ok(ranks[0], n, per, world)
+    ties = float(rng.choice([0.2, 5.0, 1e-4]))
+    for gen in range(2):
+        fit = torch.round(torch.rand(n, device="cuda", generator=g) * 200.0 / ties) * ties
+        if rng.rand() < 0.3:
+            fit[int(rng.randint(0, n))] = float("-inf")
+        new = [ref.empty(P) for _ in range(3)]
+        theta_ref, best_ref = ref.empty(n, P), ref.empty(1)
+        sigma, lr, a = float(rng.choice([0.05, 0.5])), 0.05, float(rng.uniform(0.01, 0.06))
+        ref.openai_generation(fit, 7, gen, lr, sigma, a, state, new, sigma * 0.99, gen + 1, 0, n, theta_next=theta_ref, best=best_ref)
+        torch.cuda.synchronize()
+        outs = [[es.empty(P) for _ in range(3)] for es in ranks]
+        thetas = [es.empty(min(per, n - r * per), P) for r, es in enumerate(ranks)]
+        bests = [es.empty(1) for es in ranks]
+        for r, es in enumerate(ranks):
+            with torch.cuda.stream(streams[r]):
+                es.openai_generation(fit, 7, gen, lr, sigma, a, state, outs[r], sigma * 0.99, gen + 1, r * per, thetas[r].shape[0],
+                                     theta_next=thetas[r], best=bests[r], comm=es, per_rank=per, world=world)
+        torch.cuda.synchronize()
+        for r, es in enumerate(ranks):
+            ok = ok and es.comm_p2p_status() == 0
+            ok = ok and all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(outs[r], new))
+            ok = ok and torch.equal(bests[r].view(torch.int32), best_ref.view(torch.int32))
+            ok = ok and torch.equal(thetas[r].view(torch.int32), theta_ref[r * per:r * per + thetas[r].shape[0]].view(torch.int32))
+        state = new
+    for es in ranks:
+        es.comm_p2p_detach()
+    for es in ranks + [ref]:
+        es.close()
+    return bool(ok)
 
 
 def envstep_case(rng):
@@ -121,7 +176,7 @@ def main():
             break
         done_cases += 1
         kind = rng.choice(["mlp", "mlp", "mlp", "gru", "gru", "gru_mfma", "lander", "lander", "lander_mlp", "lander_mlp", "walker",
-                           "spread", "spread", "envstep"])
+                           "spread", "spread", "envstep", "sharded_tail"])
         mode = int(rng.randint(0, 2))
         shared = bool(rng.randint(0, 2))
         sigma = float(rng.choice([0.05, 0.3, 1.0, 3.0]))
@@ -187,6 +242,9 @@ def main():
                   np.array_equal(bits(fit.cpu().numpy()), bits(ref[0])))
         elif kind == "envstep":
             ok, n, E = envstep_case(rng), 0, 1
+            es = None
+        elif kind == "sharded_tail":
+            ok, n, E = sharded_tail_case(rng), 0, 1
             es = None
         else:
             na = int(rng.choice([2, 3]))
