@@ -415,8 +415,11 @@ int ses_comm_p2p_attach(ses_handle *h, const void *handles);
  * one process; also how one test process forms worlds of 8 and 16 ranks on a single GPU): every handle exports as above, then
  * attaches the peers' HANDLES -- peers[world] in rank order, peers[rank] == h -- instead of their IPC bytes: nothing is
  * mapped, the peers' mailboxes are addressed directly, so they must live on the same device or on devices the caller has
- * enabled peer access between, each handle needs a stream of its own (an exchange kernel waits for its peers' kernels), and
- * every handle must detach before any of them is destroyed. */
+ * enabled peer access between, and every handle must detach before any of them is destroyed.  An exchange kernel WAITS for
+ * kernels of its peers: each handle needs not just a stream but a HARDWARE QUEUE of its own.  Handles on different devices
+ * have that by construction; for handles that share a device it is the runtime's choice (GPU_MAX_HW_QUEUES, default 4, and
+ * the order in which streams were created) -- two streams on one queue are a dead wait until the time-out -- so that use is
+ * for test rigs (tests/test_gpu_sharded_tail.py: one process, GPU_MAX_HW_QUEUES = ranks + 1, streams created once). */
 int ses_comm_p2p_attach_local(ses_handle *h, ses_handle *const *peers);
 int ses_comm_p2p_info(ses_handle *h, int32_t *world, int32_t *max_per_rank, int32_t *exchanges);
 /* exchanges issued over the attached transport so far, by kind: with sequence words (ses_allgather_fitness) / as granules (the

@@ -5,7 +5,7 @@ The oracle is one CPU thread per process: tools/fuzz_round.sh runs several seeds
 the GPU next to the shell) and adds the tallies up.  Box2D kinds force every kernel of the lander / walker family through
 ses_set_tuning (lanes per env 1 ... 64, one / two / four offspring per wave, episode-parallel, lockstep, MFMA), `envstep`
 drives the step-wise entries (ses_env_reset / ses_env_step_generic) against the oracle's env objects, `sharded_tail` the shard
-form of the openai_es tail on 2 or 3 in-process ranks against the replicated tail."""
+form of the openai_es tail on two in-process ranks against the replicated tail."""
 import argparse
 import json
 import os
@@ -30,18 +30,33 @@ def bits(a):
     return a.view(np.uint32 if a.dtype == np.float32 else np.uint64)
 
 
-def sharded_tail_case(rng):
+_RANK_STREAMS = []
+
+
+def sharded_tail_case(rng, force=None):
     """One random layout of the shard form of the openai_es tail (ses_openai_generation_sharded) against the replicated tail:
-    2 or 3 ranks as handles of this process on streams of their own, shards of 1-5 chunks, a ragged last shard, every policy
-    size, both rank paths (counting / sort + search) and both ways the chunk partials travel (granules / float all-gather)."""
-    world = int(rng.choice([2, 3]))
+    2 ranks as handles of this process on streams of their own, shards of 1-5 chunks, a ragged last shard, every policy size, both
+    rank paths (counting / sort + search) and both ways the chunk partials travel (granules / float all-gather).  Two ranks only:
+    an exchange kernel waits for kernels of its peer's stream, so every stream needs a hardware queue of its own, a process has four
+    by default, and five fuzz processes side by side already share the GPU's queue slots (larger worlds: tests/test_gpu_sharded_tail.py,
+    one process with GPU_MAX_HW_QUEUES = ranks + 1)."""
+    world = 2
     per = 1024 * int(rng.choice([1, 1, 2, 3, 4, 5]))
     n = world * per - int(rng.randint(0, world))
     S, A, gru = [(4, 2, False), (8, 4, False), (24, 4, False), (12, 5, False), (4, 2, True)][int(rng.randint(0, 5))]
-    streams = [torch.cuda.Stream() for _ in range(world)]
+    if force:
+        per, n, (S, A, gru) = force["per"], force["n"], force["shape"]
+    # the SAME two streams for every case of the process: which hardware queue a stream lands on is the runtime's choice, two
+    # streams that share one make an exchange kernel wait for a kernel queued behind it (observed with fresh streams per case: a
+    # dead wait every ~15 cases); a pair that works once works always
+    while len(_RANK_STREAMS) < world:
+        _RANK_STREAMS.append(torch.cuda.Stream())
+    streams = _RANK_STREAMS[:world]
     ranks = [HipES(None, S, A, A in (2, 5), gru, stream=streams[r]) for r in range(world)]
     ref = HipES(None, S, A, A in (2, 5), gru)
     granules = int(rng.randint(0, 2))
+    if force:
+        granules = force.get("granules", granules)
     for r, es in enumerate(ranks):
         es.set_tuning("comm_p2p_timeout_ms", 20000)
         es.set_tuning("openai_granule_exchange", granules)
@@ -164,6 +179,8 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--time-limit", type=float, default=0.0, help="stop drawing cases after this many seconds (0 = never)")
+    ap.add_argument("--only", default="", help="draw this kind only (e.g. sharded_tail)")
+    ap.add_argument("--skip", default="", help="never draw this kind")
     args = ap.parse_args()
     import time
     t_start = time.time()
@@ -177,6 +194,11 @@ def main():
         done_cases += 1
         kind = rng.choice(["mlp", "mlp", "mlp", "gru", "gru", "gru_mfma", "lander", "lander", "lander_mlp", "lander_mlp", "walker",
                            "spread", "spread", "envstep", "sharded_tail"])
+        if args.only:
+            kind = args.only
+        if kind == args.skip:
+            done_cases -= 1
+            continue
         mode = int(rng.randint(0, 2))
         shared = bool(rng.randint(0, 2))
         sigma = float(rng.choice([0.05, 0.3, 1.0, 3.0]))
