@@ -111,7 +111,8 @@ int ses_sync(ses_handle *h);
  * granule exchanges, the shard form of the tail then all-gathers its partials as floats), "fused_fitness_exchange" (default 1:
  * inside a sharded ses_run_generations above 8192 rows the fitness exchange needs no launch either -- the episode-mean kernel
  * stores every value as a granule into every rank's mailbox, the rank kernel polls the tiles it sorts; 0: ses_allgather_fitness
- * between rollout and tail).
+ * between rollout and tail), "fused_episode_mean" (default 1: ses_run_generations on one GPU, openai_es up to 8192 rows -- the
+ * counting rank forms the episode means itself from the rollout's per-episode returns, no episode-mean launch; 0: as two launches).
  * The library itself reads no environment variable. */
 int ses_set_tuning(ses_handle *h, const char *name, int32_t value);
 /* Timing without events: from now on the last kernel of every ses_rollout (the episode mean: end of the rollout phase)

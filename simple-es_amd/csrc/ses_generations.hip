@@ -54,6 +54,9 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
     // ... and then the fitness exchange itself needs no launch: the episode-mean kernel stores every value as a granule into every
     // rank's mailbox, the rank kernel of the tail polls the tiles it sorts (k_fitness_mean_granules, k_rank_sort_search<true>)
     const bool fused_fit = sharded_tail && openai_fused_fitness_ok(h, n, st->per_rank) == 1;
+    // one GPU, openai_es, counting rank (up to 8192 rows): the episode mean is formed inside the rank count (k_rank_count_episodes)
+    // -- ses_rollout leaves the per-episode returns, no mean kernel between the rollout and the tail
+    const bool fused_mean = !multi && openai && h->tune_fused_mean && n <= 8192;
     int rc = SES_OK;
     // The env resets depend on (env seed, generation key) only: those of all k generations are drawn up front in ONE launch
     // (keyed like ESLoop._init_states), into a buffer the handle owns -- a 4 us kernel per generation less on the
@@ -91,10 +94,14 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
             fused = grc == SES_OK;                                                      // (unsupported: RCCL only, or granules switched off)
             if (fused) { h->fit_gv = &fit_view; h->fit_own = st->fit_local; }
         }
+        unsigned long long *const rollout_stamp = h->stamp;
+        if (fused_mean) { h->skip_mean = 1; h->stamp = nullptr; }
         if (n_loc > 0)
             rc = ses_rollout(h, st->theta[cur], init, st->shared_init ? 0 : 1, n_loc, st->mode, multi ? st->fit_local : st->fitness,
                              nullptr, nullptr);
+        h->skip_mean = 0;
         if (rc != SES_OK) { h->fit_gv = nullptr; break; }
+        if (fused_mean) { h->mean_src = h->ep_return; h->mean_stamp = rollout_stamp; }
         if (multi && !fused) {
             // loop.py:66-79, the gather half of Pool.map: fitness[r * per_rank + i] = rank r's fit_local[i] (a ragged last
             // shard ends in the -inf the caller put there once)
@@ -122,6 +129,8 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
             st->pop_sigma = st->sigma;
             h->fit_gv = nullptr;
             h->fit_own = nullptr;
+            h->mean_src = nullptr;
+            h->mean_stamp = nullptr;
         } else {
             int32_t *rank = st->work_i32, *ids = rank + n, *pidx = ids + ke, *alias = pidx + ke;
             const bool evo = st->strategy == SES_STRATEGY_SIMPLE_EVOLUTION;

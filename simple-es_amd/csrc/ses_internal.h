@@ -52,6 +52,13 @@ struct ses_handle {
     // shard form of the tail consumes (k_rank_sort_search polls the tiles it sorts); fit_own: this rank's own fitness values.
     const ses::P2pGranuleView *fit_gv;
     const float *fit_own;
+    // Transient, set by ses_run_generations on ONE GPU: skip_mean -- ses_rollout leaves the episode returns in ep_return and does
+    // not launch the episode-mean kernel; mean_src -- the counting rank of ses_openai_generation forms the means itself from that
+    // array (k_rank_count_episodes) and writes fitness[]: one launch less per generation.
+    int skip_mean;
+    const double *mean_src;
+    unsigned long long *mean_stamp;   // where that kernel writes the end-of-rollout time stamp (ses_set_stamp's slot of the rollout)
+    int tune_fused_mean;           // 1 (default): ses_run_generations uses the above for openai_es up to 8192 rows on one GPU
     int lds_per_cu;                // hipDeviceAttributeMaxSharedMemoryPerMultiprocessor of the handle's device
     int env_step_key[3];           // (block, lds knob, waves knob) the two values below were resolved for
     int env_step_lds_resolved;     // the reservation actually launched with

@@ -1455,7 +1455,10 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
     } else {
         launch_cartpole_mlp(h, theta, init, init_per_offspring, n_rows, mode, epr, ep_steps);
     }
-    if (h->fit_gv)
+    if (h->skip_mean) {
+        // (ses_run_generations on one GPU: the counting rank of the tail forms the means itself, k_rank_count_episodes)
+        SES_REQUIRE(epr == h->ep_return, "ses_rollout: the fused episode mean works on the handle's own episode scratch");
+    } else if (h->fit_gv)
         hipLaunchKernelGGL(k_fitness_mean_granules, dim3(ceil_div(n_rows, 256)), dim3(256), 0, h->stream, epr, n_rows,
                            h->cfg.eval_ep_num, fitness, h->stamp, *h->fit_gv);
     else

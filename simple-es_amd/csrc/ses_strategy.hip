@@ -170,6 +170,47 @@ __global__ __launch_bounds__(256) void k_rank_count_fitness(const float *__restr
     if (il < n_own && count) atomicAdd(&rank[il], count);
 }
 
+// The same count with the episode mean folded in (ses_run_generations on one GPU, "fused_episode_mean"): no fitness vector
+// exists yet -- the rollout left its per-episode returns, float64[n, E] -- so every workgroup first forms the 64-bit keys it
+// needs from the means themselves, `jt` competitors and its own 256 rows, exactly as the episode-mean kernel forms them
+// (sequential float64 sum, / E, rounded to float32: loop.py:124), stages the competitors' keys in LDS and counts from there
+// (broadcast reads).  The workgroups of the first slice also write fitness[] (the gradient kernel and the caller read it) and
+// the first thread the time stamp the mean kernel would have written.  One launch less per generation.
+constexpr int RANK_EP_JT_MAX = 256;
+
+__global__ __launch_bounds__(256) void k_rank_count_episodes(const double *__restrict__ ep_return, int E, int n, int jt,
+                                                             int32_t *__restrict__ rank, float *__restrict__ fitness,
+                                                             unsigned long long *__restrict__ stamp)
+{
+    __shared__ unsigned long long kj[RANK_EP_JT_MAX];
+    if (stamp && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *stamp = real_time();   // end of the rollout phase
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j0 = blockIdx.y * jt;
+    const int lim = n - j0 < jt ? n - j0 : jt;
+    auto mean_of = [&](int row) {
+        double total = 0.0;
+        for (int e = 0; e < E; ++e) total += ep_return[(size_t)row * E + e];
+        return (float)(total / (double)E);
+    };
+    if ((int)threadIdx.x < lim) kj[threadIdx.x] = rank_key(f2u(mean_of(j0 + threadIdx.x)), (uint32_t)(j0 + threadIdx.x));
+    const int ic = i < n ? i : n - 1;
+    const float fi = mean_of(ic);
+    if (blockIdx.y == 0 && i < n) fitness[i] = fi;
+    const unsigned long long ki = rank_key(f2u(fi), (uint32_t)ic);
+    __syncthreads();
+    int count = 0;
+    int k = 0;
+    for (; k + 8 <= lim; k += 8) {
+        unsigned long long c[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c[e] = kj[k + e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) count += (c[e] > ki) ? 1 : 0;
+    }
+    for (; k < lim; ++k) count += (kj[k] > ki) ? 1 : 0;
+    if (i < n && count) atomicAdd(&rank[i], count);
+}
+
 // Large populations (n > RANK_SORT_MIN): sort tiles of RANK_TILE keys in LDS (bitonic network), then every
 // offspring binary-searches each sorted tile for the number of larger keys.  O(n log^2 T + n (n/T) log T)
 // instead of O(n^2).  Keys are distinct (index in the low
@@ -858,7 +899,11 @@ static int openai_generation_impl(ses_handle *h, ses_handle *comm, const float *
         h->rank_zeroed_n = n_own;
     }
     if (n_own > 0) {
-        if (count_rank) {
+        if (count_rank && !sharded && h->mean_src && jt <= RANK_EP_JT_MAX) {
+            // the episode mean inside the count (ses_run_generations): writes fitness[] for the kernels below and the caller
+            hipLaunchKernelGGL(k_rank_count_episodes, dim3(ceil_div(n, 256), ceil_div(n, jt)), dim3(256), 0, h->stream, h->mean_src,
+                               h->cfg.eval_ep_num, n, (int)jt, rank, const_cast<float *>(fitness), h->mean_stamp);
+        } else if (count_rank) {
             hipLaunchKernelGGL(k_rank_count_fitness, dim3(ceil_div(n_own, 256), ceil_div(n, jt)), dim3(256), 0, h->stream, fitness,
                                n, (int)jt, first, n_own, rank);
         } else if (sharded && fused_fit) {
