@@ -112,7 +112,9 @@ int ses_sync(ses_handle *h);
  * inside a sharded ses_run_generations above 8192 rows the fitness exchange needs no launch either -- the episode-mean kernel
  * stores every value as a granule into every rank's mailbox, the rank kernel polls the tiles it sorts; 0: ses_allgather_fitness
  * between rollout and tail), "fused_episode_mean" (default 1: ses_run_generations on one GPU, openai_es up to 8192 rows -- the
- * counting rank forms the episode means itself from the rollout's per-episode returns, no episode-mean launch; 0: as two launches).
+ * counting rank forms the episode means itself from the rollout's per-episode returns, no episode-mean launch; 0: as two launches),
+ * "fused_elite_tail" (default 1: ses_run_generations on one GPU, simple_evolution / simple_genetic up to 1024 rows -- episode mean,
+ * rank, best reward and elite selection in one launch, simple_evolution's elite rows and their mean in a second; 0: seven launches).
  * The library itself reads no environment variable. */
 int ses_set_tuning(ses_handle *h, const char *name, int32_t value);
 /* Timing without events: from now on the last kernel of every ses_rollout (the episode mean: end of the rollout phase)

@@ -57,6 +57,9 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
     // one GPU, openai_es, counting rank (up to 8192 rows): the episode mean is formed inside the rank count (k_rank_count_episodes)
     // -- ses_rollout leaves the per-episode returns, no mean kernel between the rollout and the tail
     const bool fused_mean = !multi && openai && h->tune_fused_mean && n <= 8192;
+    // one GPU, elite strategies, up to 512 rows (the reference's own configs: 97 - 257): mean + rank + best + selection in ONE
+    // launch, simple_evolution's elite rows + their mean in a second (elite_tail_small) instead of seven
+    const bool fused_elite = !multi && !openai && h->tune_fused_elite && n <= 512;   // (one workgroup counts: 512 rows = 8 waves x 512 compares)
     int rc = SES_OK;
     // The env resets depend on (env seed, generation key) only: those of all k generations are drawn up front in ONE launch
     // (keyed like ESLoop._init_states), into a buffer the handle owns -- a 4 us kernel per generation less on the
@@ -95,7 +98,7 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
             if (fused) { h->fit_gv = &fit_view; h->fit_own = st->fit_local; }
         }
         unsigned long long *const rollout_stamp = h->stamp;
-        if (fused_mean) { h->skip_mean = 1; h->stamp = nullptr; }
+        if (fused_mean || fused_elite) { h->skip_mean = 1; h->stamp = nullptr; }
         if (n_loc > 0)
             rc = ses_rollout(h, st->theta[cur], init, st->shared_init ? 0 : 1, n_loc, st->mode, multi ? st->fit_local : st->fitness,
                              nullptr, nullptr);
@@ -134,18 +137,24 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
         } else {
             int32_t *rank = st->work_i32, *ids = rank + n, *pidx = ids + ke, *alias = pidx + ke;
             const bool evo = st->strategy == SES_STRATEGY_SIMPLE_EVOLUTION;
-            rc = ses_rank_center(h, st->fitness, n, rank, nullptr, best + g);
-            if (rc == SES_OK)
-                rc = ses_elite_select(h, rank, n, ke, st->parent_map, evo ? st->alias_state : nullptr, ids, pidx, evo ? alias : nullptr);
+            if (fused_elite) {
+                rc = elite_tail_small(h, h->ep_return, n, ke, st->parent_map, evo ? st->alias_state : nullptr, rank, st->fitness, best + g,
+                                      ids, pidx, evo ? alias : nullptr, rollout_stamp, st->parents[cur], (float)st->pop_sigma, st->seed,
+                                      st->pop_gen, evo ? st->parents[nxt] : nullptr);
+            } else {
+                rc = ses_rank_center(h, st->fitness, n, rank, nullptr, best + g);
+                if (rc == SES_OK)
+                    rc = ses_elite_select(h, rank, n, ke, st->parent_map, evo ? st->alias_state : nullptr, ids, pidx, evo ? alias : nullptr);
+            }
             h->stamp = nullptr;                                                         // the elite rows are not "the next population"
             // the elite rows of the CURRENT population, rebuilt from (parents, parent map entry, row id): _select_elites
             float *rows = evo ? st->work_f32 : st->parents[nxt];
-            if (rc == SES_OK)
+            if (rc == SES_OK && !(fused_elite && evo))
                 rc = ses_perturb(h, st->parents[cur], pidx, ids, (float)st->pop_sigma, st->seed, st->pop_gen, 0, ke, rows);
             if (evo) {
                 // mu = elite[0] = the reference's in-place elite sum (offspring_strategies.py:234-248), sigma decays BEFORE the
                 // next population is drawn
-                if (rc == SES_OK) rc = ses_elite_mean(h, rows, alias, ke, st->parents[nxt]);
+                if (rc == SES_OK && !fused_elite) rc = ses_elite_mean(h, rows, alias, ke, st->parents[nxt]);
                 st->sigma = st->sigma * st->sigma_decay;
                 st->pop_sigma = st->sigma;
             } else {

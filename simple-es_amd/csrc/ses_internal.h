@@ -58,6 +58,8 @@ struct ses_handle {
     int skip_mean;
     const double *mean_src;
     unsigned long long *mean_stamp;   // where that kernel writes the end-of-rollout time stamp (ses_set_stamp's slot of the rollout)
+    int tune_fused_elite;          // 1 (default): ses_run_generations on one GPU runs the elite strategies' tail of populations up to 1024
+                                   // rows as [mean + rank + best + selection] and, simple_evolution, [elite rows + mean]: two launches for seven
     int tune_fused_mean;           // 1 (default): ses_run_generations uses the above for openai_es up to 8192 rows on one GPU
     int lds_per_cu;                // hipDeviceAttributeMaxSharedMemoryPerMultiprocessor of the handle's device
     int env_step_key[3];           // (block, lds knob, waves knob) the two values below were resolved for
@@ -155,6 +157,9 @@ __device__ __forceinline__ uint32_t granule_wait(const unsigned long long *src, 
 #endif
 
 int openai_fused_fitness_ok(const ses_handle *h, int32_t n, int32_t per_rank);     // ses_strategy.hip
+int elite_tail_small(ses_handle *h, const double *ep_return, int32_t n, int32_t k, const int32_t *parent_map, int32_t *alias_state,
+                     int32_t *rank, float *fitness, float *best, int32_t *ids, int32_t *pidx, int32_t *alias,
+                     unsigned long long *stamp, const float *parents, float sigma, uint64_t seed, uint64_t gen, float *mean_out);
 
 int ensure_episode_scratch(ses_handle *h, size_t episodes);
 int ensure_reduce_scratch(ses_handle *h, size_t bytes);

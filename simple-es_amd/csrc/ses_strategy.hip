@@ -678,6 +678,88 @@ __global__ __launch_bounds__(1024) void k_elite_select(const int32_t *__restrict
     if (j == 0 && alias_state) *alias_state = (first == 0 || (first == 1 && state != 0)) ? 1 : 0;
 }
 
+// ---- the elite strategies' tail for small populations in two launches (ses_run_generations on one GPU, n <= 1024) -----------------
+// One workgroup does what was five launches: the episode mean of every row (the rollout left its per-episode returns), the
+// counting rank with all keys in LDS, max(fitness), and ses_elite_select's bookkeeping (elite ids, their parent-map entries, the
+// aliasing flags and state of simple_evolution).  Same arithmetic and tie rule as k_fitness_mean + k_rank_keys + k_rank_count +
+// k_rank_weights + k_elite_select.  The reference's configs have 96-257 rows: a generation is latency, not work.
+__global__ __launch_bounds__(1024) void k_elite_rank_select_small(const double *__restrict__ ep_return, int E, int n, int k,
+                                                                  const int32_t *__restrict__ parent_map,
+                                                                  int32_t *__restrict__ alias_state, int32_t *__restrict__ rank,
+                                                                  float *__restrict__ fitness, float *__restrict__ best,
+                                                                  int32_t *__restrict__ elite_ids,
+                                                                  int32_t *__restrict__ elite_parent_idx,
+                                                                  int32_t *__restrict__ alias_first,
+                                                                  unsigned long long *__restrict__ stamp)
+{
+    __shared__ unsigned long long keys[1024];
+    __shared__ int32_t ids[1024];
+    const int i = threadIdx.x;
+    if (stamp && i == 0) *stamp = real_time();                           // end of the rollout phase
+    float fi = 0.0f;
+    if (i < n) {
+        double total = 0.0;
+        for (int e = 0; e < E; ++e) total += ep_return[(size_t)i * E + e];
+        fi = (float)(total / (double)E);                                 // loop.py:124
+        fitness[i] = fi;
+        keys[i] = rank_key(f2u(fi), (uint32_t)i);
+    }
+    __syncthreads();
+    if (i < n) {
+        const unsigned long long ki = keys[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += (keys[j] > ki) ? 1 : 0;
+        rank[i] = r;
+        if (r == 0 && best) *best = fi;
+        if (r < k) ids[r] = i;
+    }
+    __syncthreads();
+    const int first = ids[0];
+    const int state = alias_state ? *alias_state : 0;
+    if (i < k) {
+        const int id = ids[i];
+        elite_ids[i] = id;
+        elite_parent_idx[i] = parent_map[id];
+        if (alias_first)
+            alias_first[i] = (i > 0 && state != 0 && (first == 0 || first == 1) && (id == 0 || id == 1) && id != first) ? 1 : 0;
+    }
+    __syncthreads();                                            // every thread has read the old state
+    if (i == 0 && alias_state) *alias_state = (first == 0 || (first == 1 && state != 0)) ? 1 : 0;
+}
+
+// simple_evolution's new parent without materialising the elite rows: mean[p] = ((row_0 + row_1) + ...) / k with row_j =
+// parents[idx_j] + sigma * eps(seed, gen, ids_j, p) -- k_perturb's fma and k_elite_mean's in-place order and aliasing rule
+// (offspring_strategies.py:234-248), one thread per parameter quad, the elites' noise regenerated where it is summed.
+__global__ __launch_bounds__(64) void k_elite_mean_philox(const float *__restrict__ parents, const int32_t *__restrict__ parent_idx,
+                                                          const int32_t *__restrict__ row_ids, const int32_t *__restrict__ alias_first,
+                                                          int k, float sigma, uint64_t seed, uint64_t gen, int P, int quads,
+                                                          float *__restrict__ mean)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= quads) return;
+    const int lim = P - 4 * q < 4 ? P - 4 * q : 4;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int j = 0; j < k; ++j) {
+        const int32_t pi = parent_idx[j];
+        const float *src = parents + (size_t)(pi >= 0 ? pi : -1 - pi) * P + 4 * q;
+        float row[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (pi < 0) {
+            for (int l = 0; l < lim; ++l) row[l] = src[l];
+        } else {
+            float z[4];
+            normal4(seed, gen, (uint32_t)row_ids[j], (uint32_t)q, z);
+            for (int l = 0; l < lim; ++l) row[l] = fma_(sigma, z[l], src[l]);
+        }
+        const bool alias = j > 0 && alias_first && alias_first[j];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const float other = alias ? acc[l] : row[l];
+            acc[l] = j == 0 ? row[l] : acc[l] + other;          // offspring_strategies.py:245  mu_param += elite_param
+        }
+    }
+    for (int l = 0; l < lim; ++l) mean[4 * q + l] = acc[l] / (float)k;   // :248  param /= self.elite_num
+}
+
 __global__ void k_elite_mean(const float *__restrict__ rows, const int32_t *__restrict__ alias_first, int k, int P,
                              float *__restrict__ mean)
 {
@@ -701,6 +783,28 @@ __global__ void k_gather_rows(const float *__restrict__ src, const int32_t *__re
     dst[t] = src[(size_t)ids[i] * P + p];
 }
 
+}  // namespace ses
+
+// ses_run_generations, elite strategies on one GPU with at most 1024 rows: [episode mean + rank + best + elite selection] in one
+// launch and, for simple_evolution, [elite rows + their in-place mean] in a second (k_elite_rank_select_small,
+// k_elite_mean_philox).  rows_out != null (simple_genetic): the elite rows are materialised by ses_perturb as before.
+namespace ses {
+int elite_tail_small(ses_handle *h, const double *ep_return, int32_t n, int32_t k, const int32_t *parent_map, int32_t *alias_state,
+                     int32_t *rank, float *fitness, float *best, int32_t *ids, int32_t *pidx, int32_t *alias,
+                     unsigned long long *stamp, const float *parents, float sigma, uint64_t seed, uint64_t gen, float *mean_out)
+{
+    SES_REQUIRE(n >= 2 && n <= 1024 && k >= 1 && k <= n, "elite_tail_small: 2 <= n <= 1024, 1 <= k <= n");
+    SES_HIP_TRY(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_elite_rank_select_small, dim3(1), dim3(1024), 0, h->stream, ep_return, h->cfg.eval_ep_num, n, k, parent_map,
+                       alias_state, rank, fitness, best, ids, pidx, alias, stamp);
+    if (mean_out) {
+        const int quads = (h->P + 3) / 4;
+        hipLaunchKernelGGL(k_elite_mean_philox, dim3(ceil_div(quads, 64)), dim3(64), 0, h->stream, parents, pidx, ids, alias, k, sigma,
+                           seed, gen, h->P, quads, mean_out);
+    }
+    SES_HIP_TRY(hipGetLastError());
+    return SES_OK;
+}
 }  // namespace ses
 
 // ses_run_generations: may the fitness exchange of this layout be fused into the episode-mean kernel (producer) and
