@@ -53,7 +53,9 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
     const bool sharded_tail = multi && openai && ses_openai_sharded_ok(h, st->comm, n, st->per_rank, st->world) == 1;
     // ... and then the fitness exchange itself needs no launch: the episode-mean kernel stores every value as a granule into every
     // rank's mailbox, the rank kernel of the tail polls the tiles it sorts (k_fitness_mean_granules, k_rank_sort_search<true>)
-    const bool fused_fit = sharded_tail && openai_fused_fitness_ok(h, n, st->per_rank) == 1;
+    // (up to 8192 rows the counting rank polls them, k_rank_count_granules: also where the tail runs replicated, e.g. 4096 rows in
+    //  total over 8 ranks)
+    const bool fused_fit = multi && openai && openai_fused_fitness_ok(h, n, st->per_rank, sharded_tail ? n_loc : n) == 1;
     // one GPU, openai_es, counting rank (up to 8192 rows): the episode mean is formed inside the rank count (k_rank_count_episodes)
     // -- ses_rollout leaves the per-episode returns, no mean kernel between the rollout and the tail
     const bool fused_mean = !multi && openai && h->tune_fused_mean && n <= 8192;
@@ -95,7 +97,7 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
             const int grc = comm_p2p_granules_begin(st->comm, st->per_rank, &fit_view);
             if (grc == SES_ERR_COMM) { rc = grc; break; }
             fused = grc == SES_OK;                                                      // (unsupported: RCCL only, or granules switched off)
-            if (fused) { h->fit_gv = &fit_view; h->fit_own = st->fit_local; }
+            if (fused) { h->fit_gv = &fit_view; h->fit_own = st->fit_local; h->fit_per_rank = st->per_rank; }
         }
         unsigned long long *const rollout_stamp = h->stamp;
         if (fused_mean || fused_elite) { h->skip_mean = 1; h->stamp = nullptr; }

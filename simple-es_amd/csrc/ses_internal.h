@@ -52,6 +52,7 @@ struct ses_handle {
     // shard form of the tail consumes (k_rank_sort_search polls the tiles it sorts); fit_own: this rank's own fitness values.
     const ses::P2pGranuleView *fit_gv;
     const float *fit_own;
+    int fit_per_rank;              // rows per rank slot of that exchange
     // Transient, set by ses_run_generations on ONE GPU: skip_mean -- ses_rollout leaves the episode returns in ep_return and does
     // not launch the episode-mean kernel; mean_src -- the counting rank of ses_openai_generation forms the means itself from that
     // array (k_rank_count_episodes) and writes fitness[]: one launch less per generation.
@@ -156,7 +157,7 @@ __device__ __forceinline__ uint32_t granule_wait(const unsigned long long *src, 
 
 #endif
 
-int openai_fused_fitness_ok(const ses_handle *h, int32_t n, int32_t per_rank);     // ses_strategy.hip
+int openai_fused_fitness_ok(const ses_handle *h, int32_t n, int32_t per_rank, int32_t n_ranked);     // ses_strategy.hip
 int elite_tail_small(ses_handle *h, const double *ep_return, int32_t n, int32_t k, const int32_t *parent_map, int32_t *alias_state,
                      int32_t *rank, float *fitness, float *best, int32_t *ids, int32_t *pidx, int32_t *alias,
                      unsigned long long *stamp, const float *parents, float sigma, uint64_t seed, uint64_t gen, float *mean_out);

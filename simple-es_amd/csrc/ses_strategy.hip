@@ -211,6 +211,44 @@ __global__ __launch_bounds__(256) void k_rank_count_episodes(const double *__res
     if (i < n && count) atomicAdd(&rank[i], count);
 }
 
+// The counting rank fed by the granules of a fused fitness exchange (ses_run_generations on several ranks, up to 8192 rows): no
+// gathered vector exists -- every rank's episode-mean kernel has stored its values as granules into every rank's mailbox
+// (k_fitness_mean_granules) -- so a workgroup polls the `jt` competitors of its slice and its own 256 rows there, stages the
+// competitors' keys in LDS and counts.  The workgroups of the first row block also write fitness_all[] when the caller needs the
+// vector (the replicated tail: its gradient kernel reads the fitness of the row of rank 0).
+__global__ __launch_bounds__(256) void k_rank_count_granules(P2pGranuleView gv, int per_rank, int n, int jt, int first, int n_own,
+                                                             int32_t *__restrict__ rank, float *__restrict__ fitness_all)
+{
+    __shared__ unsigned long long kj[RANK_EP_JT_MAX];
+    const int il = blockIdx.x * 256 + threadIdx.x;
+    const int i = first + il;
+    const int j0 = blockIdx.y * jt;
+    const int lim = n - j0 < jt ? n - j0 : jt;
+    auto bits_of = [&](int row) {
+        const int owner = row / per_rank;
+        return granule_wait(gv.src + (size_t)owner * gv.section + (row - owner * per_rank), gv, owner);
+    };
+    if ((int)threadIdx.x < lim) {
+        const uint32_t u = bits_of(j0 + threadIdx.x);
+        kj[threadIdx.x] = rank_key(u, (uint32_t)(j0 + threadIdx.x));
+        if (fitness_all && blockIdx.x == 0) fitness_all[j0 + threadIdx.x] = __builtin_bit_cast(float, u);
+    }
+    const int ic = i < n ? i : n - 1;
+    const unsigned long long ki = rank_key(bits_of(ic), (uint32_t)ic);
+    __syncthreads();
+    int count = 0;
+    int k = 0;
+    for (; k + 8 <= lim; k += 8) {
+        unsigned long long c[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c[e] = kj[k + e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) count += (c[e] > ki) ? 1 : 0;
+    }
+    for (; k < lim; ++k) count += (kj[k] > ki) ? 1 : 0;
+    if (il < n_own && count) atomicAdd(&rank[il], count);
+}
+
 // Large populations (n > RANK_SORT_MIN): sort tiles of RANK_TILE keys in LDS (bitonic network), then every
 // offspring binary-searches each sorted tile for the number of larger keys.  O(n log^2 T + n (n/T) log T)
 // instead of O(n^2).  Keys are distinct (index in the low
@@ -812,9 +850,13 @@ int elite_tail_small(ses_handle *h, const double *ep_return, int32_t n, int32_t 
 // its workgroups spin until the peers' values are there, and ranks that SHARE a GPU (the test rigs) must leave room for the
 // rollouts they wait for.
 namespace ses {
-int openai_fused_fitness_ok(const ses_handle *h, int32_t n, int32_t per_rank)
+int openai_fused_fitness_ok(const ses_handle *h, int32_t n, int32_t per_rank, int32_t n_ranked)
 {
-    if (!h->tune_fused_fitness || n <= RANK_SORT_MIN || per_rank % RANK_TILE != 0) return 0;
+    // n_ranked: the rows this rank ranks (its own in the shard form of the tail, all n in the replicated one)
+    if (!h->tune_fused_fitness) return 0;
+    if (n <= RANK_SORT_MIN)                                             // counting rank: k_rank_count_granules
+        return (long long)ceil_div(n_ranked, 256) * ceil_div(n, RANK_EP_JT_MAX) <= 512 ? 1 : 0;
+    if (n_ranked == n || per_rank % RANK_TILE != 0) return 0;           // sort path: the shard form only (k_rank_sort_search<true>)
     return (long long)ceil_div(per_rank, RANK_TILE) * ceil_div(n, RANK_TILE) <= 512 ? 1 : 0;
 }
 }  // namespace ses
@@ -977,7 +1019,9 @@ static int openai_generation_impl(ses_handle *h, ses_handle *comm, const float *
     // ses_run_generations with the fitness exchange fused into its producer and consumer: no gathered vector exists, the
     // own values are at h->fit_own and every use of fitness[i] below is for an own row
     const bool fused_fit = comm != nullptr && h->fit_gv != nullptr && !count_rank;
-    if (fused_fit) fitness = h->fit_own - first_row;
+    const bool fused_cnt = h->fit_gv != nullptr && count_rank;          // the counting rank polls the granules (k_rank_count_granules)
+    float *const fitness_all = (fused_cnt && comm == nullptr) ? const_cast<float *>(fitness) : nullptr;   // replicated: the kernel writes it
+    if (fused_fit || (fused_cnt && comm != nullptr)) fitness = h->fit_own - first_row;
     const int n_own = sharded ? n_rows : n;                            // rows this rank ranks and accumulates
     const int first = sharded ? (int)first_row : 0;
     const int cl = sharded ? per_rank / ES_CHUNK : chunks;             // chunks per rank's payload
@@ -1003,7 +1047,10 @@ static int openai_generation_impl(ses_handle *h, ses_handle *comm, const float *
         h->rank_zeroed_n = n_own;
     }
     if (n_own > 0) {
-        if (count_rank && !sharded && h->mean_src && jt <= RANK_EP_JT_MAX) {
+        if (fused_cnt) {
+            hipLaunchKernelGGL(k_rank_count_granules, dim3(ceil_div(n_own, 256), ceil_div(n, RANK_EP_JT_MAX)), dim3(256), 0, h->stream,
+                               *h->fit_gv, h->fit_per_rank, n, RANK_EP_JT_MAX, first, n_own, rank, fitness_all);
+        } else if (count_rank && !sharded && h->mean_src && jt <= RANK_EP_JT_MAX) {
             // the episode mean inside the count (ses_run_generations): writes fitness[] for the kernels below and the caller
             hipLaunchKernelGGL(k_rank_count_episodes, dim3(ceil_div(n, 256), ceil_div(n, jt)), dim3(256), 0, h->stream, h->mean_src,
                                h->cfg.eval_ep_num, n, (int)jt, rank, const_cast<float *>(fitness), h->mean_stamp);

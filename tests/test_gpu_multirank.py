@@ -272,10 +272,10 @@ def test_sharded_openai_tail_equals_one_rank_bitwise(tmp_path, world, sizes, mod
     partials (and the best-reward candidates) are all-gathered through the mailboxes, the ordered update finishes --
     fitness vectors, best rewards, parent, Adam moments and the next population's rows equal the one-rank run bit for bit.
     2048 rows: counting rank; 10 239 / 12 285: one sort + search launch, last shard ragged (5119 of 5120, 3069 of 3072
-    rows).  `device_loop`: the same through ESLoop.run()'s ses_run_generations path -- above 8192 rows with BOTH exchanges of a
-    generation fused into the kernels around them (the episode-mean kernel stores the fitness granules, the rank kernel polls
-    them; the gradient kernel stores the partials, the update polls them); the last two cases switch one of the two back to an
-    all-gather launch of its own."""
+    rows).  `device_loop`: the same through ESLoop.run()'s ses_run_generations path -- with BOTH exchanges of a generation fused
+    into the kernels around them (the episode-mean kernel stores the fitness granules, the rank kernel -- counting, or sort +
+    search -- polls them; the gradient kernel stores the partials, the update polls them); the last two cases switch one of
+    the two back to an all-gather launch of its own."""
     script = tmp_path / "sh.py"
     script.write_text(SHARDED_WORKER % (ROOT, SRC))
     _run_ranks(script, tmp_path, 1, [sizes, mode])
@@ -294,7 +294,7 @@ def test_sharded_openai_tail_equals_one_rank_bitwise(tmp_path, world, sizes, mod
             assert int(got["batched_generations"]) == (5 if mode == "batched" else 0)
             # what carried the two exchanges of the 5 generations: (launches of ses_allgather_fitness, granule exchanges)
             want = {("stepwise", ""): (5, 5), ("batched", "fused_fitness_exchange=0"): (5, 5), ("batched", "openai_granule_exchange=0"): (5, 5),
-                    ("batched", ""): (5, 5) if n <= 8192 else (0, 10)}[(mode, tuning)]
+                    ("batched", ""): (0, 10)}[(mode, tuning)]
             assert tuple(int(v) for v in got["exchanges"]) == want, (n, r, mode, tuning, got["exchanges"])
         assert int(ref["batched_generations"]) == (5 if mode == "batched" else 0)
 
