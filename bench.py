@@ -413,6 +413,9 @@ def run_rank(args):
                                   "generations, the fitness all-gather issued by the C loop" if job.loop.batched_generations or
                                   getattr(job.loop, "_bench_batch", None) else
                                   "ESLoop.generation() x steps (the product loop's per-generation method), openai_es strategy object"),
+                   "value_is": ("whole-job env-steps/s of the WEAK leg: 4096 offspring per GPU, i.e. offspring_total = 4096 x n_gpus; the "
+                                "literal reading of the metric (4096 offspring in total, sharded) is strong_4096_total.value, and "
+                                "BASELINE configs[3] is c4_65536_total.value -- at n_gpus = 1 the first two coincide"),
                    "offspring_per_gpu": args.offspring_per_gpu, "offspring_total": job.n_global, "eval_ep_num": E,
                    "max_step": T, "env_steps_per_generation": job.steps_per_generation(),
                    "noise": "rocRAND philox4x32_10", "preroll_generations": preroll,
