@@ -301,7 +301,10 @@ class Job:
             ev[3].synchronize()
             rows.append([ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(3)])
         med = [statistics.median(r[i] for r in rows) for i in range(3)]
-        return {"rollout_us": med[0], "allgather_us": med[1], "fitness_loop_us": med[2]}
+        return {"rollout_us": med[0], "allgather_us": med[1], "fitness_loop_us": med[2],
+                "phases_path": "the per-generation calls (ses_rollout, ses_allgather_fitness, strategy.evaluate_async) with HIP events "
+                               "between them -- the timed loop above issues the same generation from C, where on several ranks both "
+                               "exchanges live inside the kernels around them (exchanges_per_generation)"}
 
 
 def exchange_counts(job):
