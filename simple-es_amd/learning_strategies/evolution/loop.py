@@ -125,13 +125,16 @@ class _GenerationBatch:
         self.slot = 0
         # checkpoints without draining the queue: pinned copies of the elite vector, reused round-robin (at most two are waiting)
         self.ckpt_ring = [torch.empty(P, dtype=torch.float32).pin_memory() for _ in range(4)]
-        self.ckpt_k = 0
+        self.ckpt_k = 0            # (a guarded run keeps up to comm_check_period / save_model_period of them waiting: ring grown on demand)
 
     def snapshot_elite(self, ep_num):
         """Enqueue, behind the generations issued so far, a copy of the elite's parameters (what get_elite_model() would
         return after sync_back()) into pinned host memory + an event: (generation, host vector, event).  The caller writes the
         checkpoint once the event has passed -- while the device is already working on the next chunk."""
         vec = self.keep["parents"][self.st.cur].view(-1, self.strategy.P)[0]
+        need = self.loop.comm_check_period // max(self.loop.save_model_period, 1) + 4
+        while len(self.ckpt_ring) < need:
+            self.ckpt_ring.append(torch.empty(self.strategy.P, dtype=torch.float32).pin_memory())
         host = self.ckpt_ring[self.ckpt_k]
         self.ckpt_k = (self.ckpt_k + 1) % len(self.ckpt_ring)
         host.copy_(vec, non_blocking=True)
@@ -378,19 +381,29 @@ class ESLoop(BaseESLoop):
         batch = _GenerationBatch(self, strategy, offsprings) if _GenerationBatch.eligible(self, strategy, offsprings) else None
         self._last_report = 0.0
         ep_num = 0
-        # The device-side loop of an UNGUARDED run does not drain its queue at a checkpoint generation: the elite's parameters
-        # are copied to pinned host memory by a copy enqueued behind that generation (snapshot_elite) and the file is written
-        # when the chunk is reported -- one chunk late, like the prints, while the device works on the next chunk.  (Draining
-        # cost conf/cartpole_openai.yaml, a checkpoint every 10 generations, 40 of its 254 us per generation.)
+        # The device-side loop does not drain its queue at a checkpoint generation: the elite's parameters are copied to pinned
+        # host memory by a copy enqueued behind that generation (snapshot_elite) and the file is written later -- an unguarded run
+        # writes it when the chunk is reported (one chunk late, like the prints, while the device works on the next chunk); a
+        # guarded run when the ranks have agreed, at the next boundary, that no exchange failed up to there (no checkpoint is
+        # ever written from a generation that consumed a NaN shard), so its files appear up to comm_check_period generations
+        # late.  (Draining cost conf/cartpole_openai.yaml, a checkpoint every 10 generations, 40 of its 280 us per generation.)
         chunk, ckpts = None, []
-        drain = guarded or os.environ.get("SES_DRAIN_CHECKPOINTS", "0") == "1"       # (the variable: A/B runs of the old behaviour)
+        drain = os.environ.get("SES_DRAIN_CHECKPOINTS", "0") == "1"       # (A/B runs of the old behaviour: drain at every checkpoint)
+
+        def next_checkpoint(ep):
+            return (ep // period + 1) * period
+
         while ep_num < self.generation_num:
-            boundary = min(self.generation_num, (ep_num // period + 1) * period)
+            # where the queue is drained: the end; a guarded run's agreement points; per-generation segments and
+            # SES_DRAIN_CHECKPOINTS=1 also at every checkpoint generation (their checkpoints are written synchronously)
+            hard = self.generation_num
             if guarded:
-                boundary = min(boundary, snap[0] + self.comm_check_period)
+                hard = min(hard, snap[0] + self.comm_check_period)
+            if batch is None or drain:
+                hard = min(hard, next_checkpoint(ep_num))
             if batch is not None:
-                while ep_num < boundary:
-                    k = min(batch.K_MAX, boundary - ep_num)
+                while ep_num < hard:
+                    k = min(batch.K_MAX, hard - ep_num, next_checkpoint(ep_num) - ep_num)
                     t0 = time.time()
                     best, stamps, sigmas = batch.run(k)
                     self.batched_generations += k
@@ -399,16 +412,17 @@ class ESLoop(BaseESLoop):
                         ckpts.append(batch.snapshot_elite(ep_num))
                     if chunk is not None:
                         self._report_chunk(chunk, rank0)
-                        self._write_checkpoints(ckpts, chunk[0] + chunk[1] - 1, strategy)
+                        if not guarded:
+                            self._write_checkpoints(ckpts, chunk[0] + chunk[1] - 1, strategy)
                     chunk = (ep_num - k + 1, k, best, stamps, sigmas, t0)
-                if drain or ep_num >= self.generation_num:
-                    self._report_chunk(chunk, rank0)   # a boundary generation is reported before anything is written
+                self._report_chunk(chunk, rank0)       # a boundary generation is reported before anything is written
+                chunk = None
+                if not guarded:
                     self._write_checkpoints(ckpts, ep_num, strategy)
-                    chunk = None
-                    offsprings = batch.sync_back()
+                offsprings = batch.sync_back()
             else:
                 pending = None
-                while ep_num < boundary:
+                while ep_num < hard:
                     ep_num += 1
                     start_time = time.time()
                     offsprings, best, curr_sigma, events = self.generation(offsprings)
@@ -424,12 +438,14 @@ class ESLoop(BaseESLoop):
                     self.ep5_rewards.clear()
                     self.ep5_rewards.extend(snap[3])
                     self._prev_tail = 0
+                    ckpts[:] = [c for c in ckpts if c[0] <= ep_num]      # snapshots of the generations that will be replayed
                     if rank0 and self._metrics is not None:      # the rows of the replayed generations above this one are void
                         self._metrics.write(json.dumps({"rollback_to": ep_num}) + "\n")
                     # the transport has changed: the device-side loop continues only if a library transport is left
                     batch = (_GenerationBatch(self, strategy, offsprings)
                              if _GenerationBatch.eligible(self, strategy, offsprings) else None)
                     continue
+                self._write_checkpoints(ckpts, ep_num, strategy)         # every rank's exchanges up to here were good
                 snap = (ep_num, strategy.snapshot(offsprings), len(self.history), list(self.ep5_rewards))
             if ep_num % period == 0 and rank0 and (drain or batch is None):
                 elite = strategy.get_elite_model()
