@@ -93,7 +93,13 @@ WORKER = textwrap.dedent("""
 def test_sharded_tail_equals_replicated_tail_bitwise(tmp_path, world, per, missing, gru, granules):
     script = tmp_path / "tail.py"
     script.write_text(WORKER % (ROOT, SRC))
-    run = subprocess.run(["timeout", "-k", "10", "300", sys.executable, str(script), str(world), str(per), str(missing), str(gru), str(granules)],
-                         capture_output=True, text=True, timeout=400)
+    cmd = ["timeout", "-k", "10", "300", sys.executable, str(script), str(world), str(per), str(missing), str(gru), str(granules)]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=400)
+    if run.returncode != 0 and "an exchange timed out" in run.stderr:
+        # Ranks as handles of ONE process on ONE device are a rig: an exchange kernel waits for kernels of its peers' streams, and
+        # which hardware queue a stream lands on is the runtime's choice (two on one queue: a dead wait until the 5 s time-out --
+        # include/ses.h, ses_comm_p2p_attach_local).  A time-out here says nothing about the arithmetic under test: once more.
+        print("in-process rig: an exchange timed out (hardware-queue placement), running the case once more")
+        run = subprocess.run(cmd, capture_output=True, text=True, timeout=400)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
     assert run.stdout.strip().endswith(f"ok {world} {per} {world * per - missing}")
