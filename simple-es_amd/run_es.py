@@ -50,9 +50,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         import torch.distributed as dist
-        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("SES_DIST_BACKEND", "nccl") == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:                           # test rigs where the ranks share one GPU (RCCL refuses duplicate devices): gloo control plane,
+            dist.init_process_group(os.environ["SES_DIST_BACKEND"])      # the fitness exchange stays the library's peer stores
 
     set_seed(args.seed)
     with open(args.cfg_path) as f:

@@ -439,3 +439,29 @@ def test_an_unguarded_caller_fails_loudly_after_a_timed_out_exchange(tmp_path):
     r0 = open(tmp_path / "ug_r0.txt").read()
     assert r0.startswith("nan_shard=True failed=True raised:") and "timed out" in r0 and "code -5" in r0, r0
     assert open(tmp_path / "ug_r1.txt").read() == "late rank: ok"
+
+
+def test_run_es_command_line_on_two_ranks(tmp_path):
+    """`python -m torch.distributed.run ... run_es.py --cfg-path conf/cartpole_openai.yaml` -- the reference's command line
+    (run_es.py:15-62) with the population sharded over two ranks (here: sharing the GPU, gloo control plane): same printed
+    best rewards and the same checkpoints as the one-rank command, only rank 0 prints and writes."""
+    import re
+    import shutil
+    outs = {}
+    for world in (1, 2):
+        work = tmp_path / f"w{world}"
+        shutil.copytree(SRC, work, ignore=shutil.ignore_patterns("logs", "__pycache__", "_obj"))
+        args = ["run_es.py", "--cfg-path", "conf/cartpole_openai.yaml", "--generation-num", "12", "--offspring-num", "2048",
+                "--save-model-period", "5", "--seed", "3"]
+        cmd = ([sys.executable] + args if world == 1 else
+               [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(free_port())] + args)
+        run = subprocess.run(cmd, cwd=work, capture_output=True, text=True, timeout=900,
+                             env={**os.environ, "SES_DIST_BACKEND": "gloo", "SES_COMM_P2P": "1"})
+        assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
+        lines = [l for l in run.stdout.splitlines() if l.startswith("episode:")]
+        assert len(lines) == 12, run.stdout[-2000:]                    # rank 0 only
+        outs[world] = [re.match(r"episode: (\d+), Best reward: ([-0-9.]+), sigma: ([0-9.]+)", l).groups() for l in lines]
+        saved = sorted(p.name for p in work.glob("logs/*/*/saved_models/*.pt"))
+        assert saved == ["ep_10.pt", "ep_5.pt"], saved
+    assert outs[1] == outs[2]
