@@ -878,7 +878,7 @@ __global__ __launch_bounds__(64) void k_rollout_spread_mlp(const float *__restri
             net.forward(tanh_tab, obs, logits);
             action[a] = argmax_first<A>(logits);
         }
-        ret += (double)spread_step<NA>(st, action);
+        ret += (double)spread_step<NA, true>(st, action, sub & 3);
     }
     if (valid && sub == 0) ep_return[env] = ret;
 }

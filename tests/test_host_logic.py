@@ -173,3 +173,20 @@ def sweep_main_help():
         assert out.returncode == 0, out.stderr
         _HELP["out"] = out.stdout
     return _HELP["out"]
+
+
+def test_spread_collision_threshold_is_where_the_root_reaches_the_contact_distance():
+    """csrc/ses_spread.h counts collisions on the SQUARED distance: s < SP_DIST_MIN_SQ must say what sqrtf(s) < 0.3f says
+    (oracle/ses_oracle.c::spread_step) for every float s -- true when the constant is the smallest float whose correctly
+    rounded root reaches 0.3f, sqrtf being monotonic."""
+    import re
+    import numpy as np
+    text = open(os.path.join(SRC, "csrc", "ses_spread.h")).read()
+    t = np.float32(float.fromhex(re.search(r"SP_DIST_MIN_SQ = (0x[0-9a-fA-F.]+p[-+]?\d+)f;", text).group(1)))
+    d = np.float32(float(re.search(r"SP_DIST_MIN = ([0-9.]+)f;", text).group(1)))
+    assert d == np.float32(0.3)
+    assert np.sqrt(t) >= d and np.sqrt(np.nextafter(t, np.float32(0))) < d
+    # and the roots around it are ordered as their arguments (a window of 2^16 floats on either side)
+    s = (t.view(np.uint32) + np.arange(-65536, 65536, dtype=np.int64)).astype(np.uint32).view(np.float32)
+    r = np.sqrt(s)
+    assert np.all(np.diff(r) >= 0) and np.array_equal(r < d, s < t)
