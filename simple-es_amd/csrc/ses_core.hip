@@ -138,6 +138,7 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     h->tune_fused_fitness = 1;
     h->tune_fused_mean = 1;
     h->tune_fused_elite = 1;
+    h->tune_fused_apply_perturb = 1;
     h->tune_comm_granules = 0;                // measured: 12.4 us against 6.3 for the kernel with sequence words (4096 floats, two ranks)
     h->tune_es_final_max_chunks = 0;          // measured: the wave-per-parameter update launch beats the in-kernel finisher
     *out = h;
@@ -175,7 +176,8 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"comm_granules_enabled", &ses_handle::tune_comm_granules_enabled, 0, 1},
                                  {"fused_fitness_exchange", &ses_handle::tune_fused_fitness, 0, 1},
                                  {"fused_episode_mean", &ses_handle::tune_fused_mean, 0, 1},
-                                 {"fused_elite_tail", &ses_handle::tune_fused_elite, 0, 1}};
+                                 {"fused_elite_tail", &ses_handle::tune_fused_elite, 0, 1},
+                                 {"fused_apply_perturb", &ses_handle::tune_fused_apply_perturb, 0, 1}};
     for (const Knob &k : knobs) {
         if (std::strcmp(k.name, name) == 0) {
             SES_REQUIRE(value >= k.lo && value <= k.hi, "ses_set_tuning: %s = %d outside [%d, %d]", name, value, k.lo, k.hi);
