@@ -113,7 +113,7 @@ int ses_sync(ses_handle *h);
  * stores every value as a granule into every rank's mailbox, the rank kernel polls the tiles it sorts; 0: ses_allgather_fitness
  * between rollout and tail), "fused_episode_mean" (default 1: ses_run_generations on one GPU, openai_es up to 8192 rows -- the
  * counting rank forms the episode means itself from the rollout's per-episode returns, no episode-mean launch; 0: as two launches),
- * "fused_elite_tail" (default 1: ses_run_generations on one GPU, simple_evolution / simple_genetic up to 1024 rows -- episode mean,
+ * "fused_elite_tail" (default 1: ses_run_generations on one GPU, simple_evolution / simple_genetic up to 512 rows -- episode mean,
  * rank, best reward and elite selection in one launch, simple_evolution's elite rows and their mean in a second; 0: seven launches),
  * "fused_apply_perturb" (default 1: ses_openai_generation, replicated form, policies up to 1024 parameters and populations up to
  * 16 384 rows -- every workgroup of the launch that writes the next population applies the Adam update itself; 0: a launch of its own).
