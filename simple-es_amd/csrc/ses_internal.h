@@ -60,7 +60,7 @@ struct ses_handle {
     const double *mean_src;
     unsigned long long *mean_stamp;   // where that kernel writes the end-of-rollout time stamp (ses_set_stamp's slot of the rollout)
     int tune_fused_elite;          // 1 (default): ses_run_generations on one GPU runs the elite strategies' tail of populations up to 512
-                                   // rows (the kernel serves 1024; one workgroup counts, and beyond 512 the seven launches are faster) as [mean + rank + best + selection] and, simple_evolution, [elite rows + mean]: two launches for seven
+                                   // rows (the kernel serves 1024; ONE workgroup counts -- n compares per row -- so the loop stops using it at 512, twice the reference's largest config) as [mean + rank + best + selection] and, simple_evolution, [elite rows + mean]: two launches for seven
     int tune_fused_apply_perturb;  // 1 (default): the replicated openai_es tail of policies up to 1024 parameters applies the update inside the
                                    // launch that writes the next population (k_es_apply_perturb): one launch less per generation
     int tune_fused_mean;           // 1 (default): ses_run_generations uses the above for openai_es up to 8192 rows on one GPU
