@@ -462,11 +462,14 @@ int ses_allgather_fitness(ses_handle *h, const float *local, int32_t n_per_rank,
         SES_HIP_TRY(hipSetDevice(h->cfg.device));
         P2pGranuleView gv;
         const int grc = comm_p2p_granules_begin(h, n_per_rank, &gv);
-        if (grc != SES_OK) return grc;
-        hipLaunchKernelGGL(k_allgather_granules, dim3(gv.world, ceil_div(n_per_rank, P2P_SPLIT)), dim3(256), 0, h->stream, local,
-                           (int)n_per_rank, gv, all);
-        SES_HIP_TRY(hipGetLastError());
-        return SES_OK;
+        if (grc == SES_OK) {
+            hipLaunchKernelGGL(k_allgather_granules, dim3(gv.world, ceil_div(n_per_rank, P2P_SPLIT)), dim3(256), 0, h->stream, local,
+                               (int)n_per_rank, gv, all);
+            SES_HIP_TRY(hipGetLastError());
+            return SES_OK;
+        }
+        if (grc != SES_ERR_UNSUPPORTED) return grc;
+        // granules switched off for this transport (comm_granules_enabled = 0 after a failed self-test): the flag-based kernel below
     }
     if (h->p2p && h->p2p->attached && n_per_rank <= h->p2p->max_per_rank && !(h->tune_comm_force_rccl && h->comm)) {
         ses_p2p *p = h->p2p;

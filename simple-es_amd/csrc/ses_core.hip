@@ -129,7 +129,11 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     h->env_step_key[0] = -2;
     {
         int lds = 0;
-        SES_HIP_TRY(hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, cfg->device));
+        const hipError_t e = hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, cfg->device);
+        if (e != hipSuccess) {
+            delete h;                         // nothing else is owned yet
+            return ses::set_error(SES_ERR_HIP, "ses_create: hipDeviceGetAttribute: %s", hipGetErrorString(e));
+        }
         h->lds_per_cu = lds;
     }
     h->tune_openai_sharded_tail = 1;

@@ -1089,9 +1089,10 @@ static int openai_generation_impl(ses_handle *h, ses_handle *comm, const float *
     // first time (or whenever the scratch moved, or the layout / population size changed).
     if (n_own > 0 && (h->rank_zeroed != rank || h->rank_zeroed_n != n_own)) {
         SES_HIP_TRY(hipMemsetAsync(rank, 0, sizeof(int32_t) * (size_t)n_own, h->stream));
-        h->rank_zeroed = rank;
-        h->rank_zeroed_n = n_own;
     }
+    // From here to the launch that clears it again the vector holds counts: every early return below (a failed
+    // exchange, a launch error) leaves the cache saying "not zero", so the next call starts with the memset.
+    h->rank_zeroed = nullptr;
     double uf = lr / ((double)n * sigma);            // offspring_strategies.py:406-408
     uf *= -1.0;
     const bool final_in_grad = !sharded && chunks <= h->tune_es_final_max_chunks;   // Adam by the gradient kernel's finishing workgroups
@@ -1167,6 +1168,8 @@ static int openai_generation_impl(ses_handle *h, ses_handle *comm, const float *
                                    (float)uf, adam_a, mu_in, m_in, v_in, mu_out, m_out, v_out, next_sigma, seed, next_gen,
                                    (long long)first_row, n_rows, h->P, quads, theta_next, h->stamp, rank, n_own);
                 SES_HIP_TRY(hipGetLastError());
+                h->rank_zeroed = rank;
+                h->rank_zeroed_n = n_own;
                 return SES_OK;
             }
             hipLaunchKernelGGL(k_es_apply, dim3(ceil_div(h->P, 4)), dim3(256), 0, h->stream, partial, chunks, h->P, P4,
@@ -1181,6 +1184,8 @@ static int openai_generation_impl(ses_handle *h, ses_handle *comm, const float *
                            next_gen, (long long)first_row, n_rows, h->P, quads, theta_next, h->stamp, rank, n_own);
     }
     SES_HIP_TRY(hipGetLastError());
+    h->rank_zeroed = rank;              // cleared by the launch above
+    h->rank_zeroed_n = n_own;
     return SES_OK;
 }
 

@@ -325,8 +325,167 @@ def g8_lander():
     print("G8 lander", float(np.mean(rets)), float(np.min(rets)), float(np.max(rets)))
 
 
+# --------------------------------------------------------------------------- G9 (long-lived policies)
+class _EpisodeLog:
+    """Mixin for the build's replay envs: remembers how many steps each episode of the reference's RolloutWorker took
+    (RolloutWorker itself only hands back the mean return, loop.py:124-125)."""
+
+    def reset(self):
+        if getattr(self, "curr_step", 0):
+            self.lengths.append(self.curr_step)
+        return super().reset()
+
+    def take_lengths(self):
+        if self.curr_step:
+            self.lengths.append(self.curr_step)
+        out, self.lengths, self.curr_step = self.lengths, [], 0
+        return out
+
+
+def g9_long():
+    """Policies that LIVE: the regime the headline benchmark (500 steps per episode) and the reference's only published
+    result (README.md:42, GRU reaching 500 on POMDP CartPole) run in.  G5 / G8 are random or barely trained policies
+    (median episode 12 steps); here the parameter vectors come from tests/golden/g9_seeds.npz -- elite vectors of product
+    training runs, harvested by tools/g9_train.py, INPUT data -- and seeded perturbations of them; every return is
+    produced by the reference's RolloutWorker + GymEnvModel over the build's replay envs, exactly like G5 / G8.
+
+    SES_G9_STRIDE=k regenerates every k-th policy only (the regeneration test: the full set is ~2 minutes of reference
+    rollouts); row i of a strided run is row i*k of the committed file."""
+    from oracle.lander_env import LunarLanderEnv
+    stride = int(os.environ.get("SES_G9_STRIDE", "1"))
+    seeds = np.load(os.path.join(HERE, "g9_seeds.npz"))
+    out, meta = {}, {"stride": stride}
+    E = 5
+    init = np.random.RandomState(0).uniform(-0.05, 0.05, (E, 4)).astype(np.float32)
+    out["init_states"] = init
+
+    class Cart(_EpisodeLog, CartPoleF32Env):
+        lengths = []
+
+    class Lander(_EpisodeLog, LunarLanderEnv):
+        lengths = []
+
+    def returns_of(env, net, theta, episodes):
+        rets, steps = [], []
+        env.lengths = []
+        for i in range(theta.shape[0]):
+            load_flat(net, theta[i])
+            env.rewind()
+            env.curr_step = 0
+            rets.append(RolloutWorker((env, {"0": net}, episodes)))
+            steps.append(env.take_lengths())
+        return np.array(rets, dtype=np.float64), np.array(steps, dtype=np.int32)
+
+    # (a) CartPole-v1, MLP: the 35 checkpoint vectors and nine noise levels around each of them
+    rng = np.random.RandomState(9)
+    mlp = seeds["mlp"]
+    theta = np.concatenate([mlp] + [(mlp + rng.standard_normal(mlp.shape) * sg).astype(np.float32)
+                                    for sg in (0.05, 0.1, 0.15, 0.2, 0.35, 0.5, 0.8, 1.2)])
+    theta = np.ascontiguousarray(theta[::stride], dtype=np.float32)
+    r, st = returns_of(Cart(init, max_step=500), GymEnvModel(4, 2, True, False), theta, E)
+    out["mlp_theta"], out["mlp_returns"], out["mlp_steps"] = theta, r, st
+    meta["mlp"] = {"N": int(len(r)), "E": E, "at_cap": int((r == 500).sum()), "ge50_lt500": int(((r >= 50) & (r < 500)).sum()),
+                   "env_steps": int(st.sum())}
+    print("G9 mlp", meta["mlp"], flush=True)
+
+    # (b) POMDP CartPole-v1, GRU (README.md:42): 20 checkpoints of one simple_evolution run + two noise levels
+    rng = np.random.RandomState(10)
+    gru = seeds["gru"]
+    theta = np.concatenate([gru] + [(gru + rng.standard_normal(gru.shape) * sg).astype(np.float32) for sg in (0.02, 0.05)])[:48]
+    theta = np.ascontiguousarray(theta[::stride], dtype=np.float32)
+    netg = GymEnvModel(4, 2, True, True)
+    r, st = returns_of(Cart(init, max_step=500, pomdp=True), netg, theta, E)
+    out["gru_theta"], out["gru_returns"], out["gru_steps"] = theta, r, st
+    meta["gru"] = {"N": int(len(r)), "E": E, "at_cap": int((r == 500).sum()), "ge100": int((r >= 100).sum()),
+                   "env_steps": int(st.sum())}
+    print("G9 gru", meta["gru"], flush=True)
+
+    # (c) LunarLanderContinuous-v2 POMDP, GRU, openai_es checkpoints (conf/lunarlander_openai.yaml shape): policies that
+    #     stay in the air for all 300 steps or land
+    El = 3
+    init_l = np.random.RandomState(8).rand(El, 16).astype(np.float32)
+    theta = np.ascontiguousarray(seeds["lander"][::stride], dtype=np.float32)
+    netl = GymEnvModel(8, 4, False, True)
+    r, st = returns_of(Lander(init_l, max_step=300, pomdp=True), netl, theta, El)
+    out["lander_theta"], out["lander_init"], out["lander_returns"], out["lander_steps"] = theta, init_l, r, st
+    meta["lander"] = {"N": int(len(r)), "E": El, "policies_flying_300_in_every_episode": int((st.min(axis=1) == 300).sum()),
+                      "episodes_at_300": int((st == 300).sum()), "max_return": float(r.max()), "env_steps": int(st.sum())}
+    # The reference's OWN sensitivity at this horizon: the same rollouts with every parameter moved to a neighbouring
+    # float32 (one ulp up or down, seeded).  A continuous-action episode that bounces on its legs amplifies a last-bit
+    # difference of one action into a different contact sequence; how far the reference's return moves under a change
+    # that small is the yardstick for a build whose tanh and summation order differ from ATen's in the last bit.
+    rng = np.random.RandomState(11)
+    K = 3
+    r_ulp, st_ulp = [], []
+    for k in range(K):
+        up = rng.rand(*seeds["lander"].shape) < 0.5
+        moved = np.where(up, np.nextafter(seeds["lander"], np.float32(np.inf)), np.nextafter(seeds["lander"], np.float32(-np.inf)))
+        rk, sk = returns_of(Lander(init_l, max_step=300, pomdp=True), netl, np.ascontiguousarray(moved[::stride], dtype=np.float32), El)
+        r_ulp.append(rk)
+        st_ulp.append(sk)
+    out["lander_returns_ulp"], out["lander_steps_ulp"] = np.stack(r_ulp), np.stack(st_ulp)
+    meta["lander"]["ulp_variants"] = K
+    meta["lander"]["max_abs_move_of_the_reference_under_one_ulp"] = float(np.abs(out["lander_returns_ulp"] - r).max())
+    print("G9 lander", meta["lander"], flush=True)
+
+    # (d) closed-loop trajectories of the reference module, one whole episode each: observations as the policy saw them,
+    #     hidden state after every step, pre-activation outputs, actions
+    def trajectory(env, net, vec, T, A_out):
+        load_flat(net, vec)
+        env.rewind()
+        states = env.reset()
+        net.reset()
+        S = states["0"]["state"].shape[0]
+        obs = np.zeros((T, S), np.float32)
+        hid = np.zeros((T, 32), np.float32)
+        logits = np.zeros((T, net.fc2.out_features), np.float32)
+        act = np.zeros((T, A_out), np.float32)
+        n = 0
+        done = False
+        while not done:
+            o = np.asarray(states["0"]["state"], dtype=np.float32)
+            obs[n] = o
+            h_before = net.h.clone()
+            a = net(o[np.newaxis, ...])
+            with torch.no_grad():
+                x = torch.tanh(net.fc1(torch.from_numpy(o[np.newaxis, ...]).float().unsqueeze(0)))
+                x, _ = net.gru(x, h_before)
+                logits[n] = net.fc2(torch.tanh(x)).numpy().reshape(-1)
+            hid[n] = net.h.numpy().reshape(-1)
+            act[n] = a
+            states, _, done, _ = env.step({"0": a})
+            n += 1
+        return obs, hid, logits, act, n
+
+    if stride == 1:
+        rows = [8, 12, 16, 19]                       # checkpoints of generations 72 .. 160: at the cap
+        tr = [trajectory(CartPoleF32Env(init, max_step=500, pomdp=True), netg, seeds["gru"][k], 500, 1) for k in rows]
+        out["traj_gru_theta"] = np.ascontiguousarray(seeds["gru"][rows])
+        for j, key in enumerate(("obs", "h", "logits", "act")):
+            out[f"traj_gru_{key}"] = np.stack([t[j] for t in tr])
+        out["traj_gru_len"] = np.array([t[4] for t in tr], dtype=np.int32)
+        rows = [9, 12]
+        tr = []                                      # the second reset row: every checkpoint from generation 100 on flies it out
+        for k in rows:
+            env = LunarLanderEnv(np.roll(init_l, -1, axis=0), max_step=300, pomdp=True)
+            tr.append(trajectory(env, netl, seeds["lander"][k], 300, 4))
+        out["traj_lander_theta"] = np.ascontiguousarray(seeds["lander"][rows])
+        out["traj_lander_init"] = np.roll(init_l, -1, axis=0)[:1].copy()
+        for j, key in enumerate(("obs", "h", "logits", "act")):
+            out[f"traj_lander_{key}"] = np.stack([t[j] for t in tr])
+        out["traj_lander_len"] = np.array([t[4] for t in tr], dtype=np.int32)
+        meta["traj"] = {"gru_len": [int(t) for t in out["traj_gru_len"]], "lander_len": [int(t) for t in out["traj_lander_len"]]}
+        print("G9 trajectories", meta["traj"], flush=True)
+
+    np.savez_compressed(os.path.join(OUT, "g9_long.npz"), **out)
+    with open(os.path.join(OUT, "g9_long.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g234", "g56", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g234", "g56", "g7", "g8", "g9"]
+    if "g9" in which:
+        g9_long()
     if "g8" in which:
         g8_lander()
     if "g7" in which:

@@ -209,18 +209,34 @@ def test_physics64_closes_most_of_the_gap_to_gym_float64(g56):
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree only exists in the build container")
 def test_committed_fixtures_are_what_the_generator_produces(tmp_path):
-    """tests/golden/make_golden.py (imports the reference) regenerates every committed fixture bit for bit."""
+    """tests/golden/make_golden.py (imports the reference) regenerates every committed fixture bit for bit.  Of G9 (two
+    minutes of reference rollouts) every 6th policy is regenerated and compared with its row of the committed file."""
     import subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
+    stride = 6
     out = subprocess.run([sys.executable, os.path.join(here, "golden", "make_golden.py")], capture_output=True, text=True,
-                         env={**os.environ, "SES_GOLDEN_OUT": str(tmp_path)}, timeout=1500)
+                         env={**os.environ, "SES_GOLDEN_OUT": str(tmp_path), "SES_G9_STRIDE": str(stride)}, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
-    names = sorted(f for f in os.listdir(os.path.join(here, "golden")) if f.endswith((".npz", ".json")))
+    inputs = {"g9_seeds.npz"}            # parameter vectors harvested from product training runs (tools/g9_train.py): data the generator READS
+    names = sorted(f for f in os.listdir(os.path.join(here, "golden")) if f.endswith((".npz", ".json")) and f not in inputs)
     assert names and sorted(f for f in os.listdir(tmp_path) if f.endswith((".npz", ".json"))) == names
     for f in names:
         a, b = os.path.join(here, "golden", f), os.path.join(tmp_path, f)
-        if f.endswith(".json"):
+        if f == "g9_long.json":
+            assert json.load(open(a))["stride"] == 1 and json.load(open(b))["stride"] == stride
+        elif f.endswith(".json"):
             assert json.load(open(a)) == json.load(open(b)), f
+        elif f == "g9_long.npz":
+            x, y = np.load(a), np.load(b)
+            assert set(y.files) == {k for k in x.files if not k.startswith("traj_")}, f      # (the trajectories: full runs only)
+            for k in y.files:
+                want = x[k]
+                if k.endswith("_ulp"):
+                    want = want[:, ::stride]
+                elif k.split("_")[0] in ("mlp", "gru") or k in ("lander_theta", "lander_returns", "lander_steps"):
+                    want = want[::stride]
+                assert want.dtype == y[k].dtype and want.shape == y[k].shape, (f, k)
+                assert np.ascontiguousarray(want).tobytes() == y[k].tobytes(), (f, k)
         else:
             x, y = np.load(a), np.load(b)
             assert set(x.files) == set(y.files), f
