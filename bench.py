@@ -61,7 +61,7 @@ PARITY_NOTE = ("CartPole (the headline): rollout returns bit-exact vs the C orac
                "over the build's own fp32 CartPole (fixture G5: random / barely trained policies, median episode 12 steps) AND on "
                "long-lived ones (fixture G9, trained checkpoints + perturbations: 315 MLP policies, 186 at the 500 cap, 75 between "
                "50 and 500; 48 POMDP GRU policies, 19 at the cap): measured exact-match rate 363 / 363 = 100 %, every one of the "
-               "1815 episode lengths equal, i.e. no argmax flipped in 634 000 reference env steps; GRU hidden state along whole "
+               "1815 episode lengths equal, i.e. no argmax flipped in 633 000 reference env steps; GRU hidden state along whole "
                "500-step reference episodes within 5e-6 per step teacher-forced, no action flip free-running.  Vs a gym-faithful "
                "float64 CartPole the same return for 95 % of "
                "the G5 policies (99.2 % with env.physics: float64) -- gym itself is not pinned by the reference.  "

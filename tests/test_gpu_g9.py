@@ -3,7 +3,7 @@ and GRU trajectories from the imported reference, tests/golden/make_golden.py g9
 
 Bars: device == C oracle BIT FOR BIT (fitness, per-episode returns, episode lengths) in both rollout modes and for every
 lanes-per-env variant of the MLP kernel; device vs the reference: CartPole returns within 1e-4 (north_star) -- at these
-horizons that means no argmax flipped in 634 000 env steps -- and LunarLander as tests/test_oracle_g9.py states it
+horizons that means no argmax flipped in 633 000 env steps -- and LunarLander as tests/test_oracle_g9.py states it
 (episode lengths equal; returns inside the reference's own one-ulp sensitivity)."""
 import os
 

@@ -8,7 +8,7 @@ perturbations of them; its returns, episode lengths and hidden-state trajectorie
 
 Bars:
   * CartPole MLP (315 policies, 186 at the 500 cap) and POMDP-CartPole GRU (48 policies, 19 at the cap): every return
-    within 1e-4 (north_star) and every episode length EQUAL -- i.e. not a single argmax flipped in 634 000 env steps.
+    within 1e-4 (north_star) and every episode length EQUAL -- i.e. not a single argmax flipped in 633 000 env steps.
   * 500-step / 300-step closed-loop trajectories of the reference GRU module: teacher-forced per-step agreement as in G1
     (|dh| <= 1e-5); free-running (the oracle carries its own hidden state for the whole episode) no action flips.
   * LunarLander GRU (continuous actions, policies that fly all 300 steps or land): episode lengths equal; returns of
