@@ -18,11 +18,12 @@ method `ESLoop.run()` (and therefore `run_es.py`) loops over, everything on devi
 Parameters, Adam moments and the population are resident in HBM before the timed region.
 
 Three population sizes are measured per run (`value` is the first):
-    weak      4096 offspring PER GPU   (per-GPU work fixed: "scaling": "weak")
-    strong    4096 offspring in total  (the literal reading of BASELINE.json's metric)
+    strong    4096 offspring in total  (BASELINE.json's metric as written, "pop=4096 at 1/2/4/8 GPUs": "scaling": "strong")
+    weak      4096 offspring PER GPU   (per-GPU work fixed; the same job at N = 1)
     c4        65 536 offspring in total (BASELINE.json configs[3])
-each with the transport of the all-gather, its time and the per-rank fitness-loop time; at N > 1 also
-`allgather_microbench` (the exchange alone over each transport).
+each with the transport of the all-gather, its time and the per-rank fitness-loop time, and at N > 1 each with a `*_rccl` twin:
+the same generations with both exchanges forced onto ncclAllGather ("absent" where no RCCL communicator spans the ranks);
+at N > 1 also `allgather_microbench` (the exchange alone over each transport).  `e1`: the headline job with --eval-ep-num 1.
 
 Extra legs (rank 0): `roofline` -- the standalone SoA env-step kernel at 2^24 envs against the HBM roof
 (SURVEY 8d: 52 algorithmic bytes per env-step), timed with HIP events on the launch stream;
@@ -392,8 +393,9 @@ def run_rank(args):
     os.chdir(work)
     preroll = args.preroll if args.preroll >= 0 else max(0, 300 - args.warmup)
 
-    # ---- headline: weak scaling, 4096 offspring per GPU ---------------------------------------------------------
-    job = Job(args, args.offspring_per_gpu * world, world)
+    # ---- headline: BASELINE's metric as written -- 4096 offspring IN TOTAL, sharded over the GPUs (strong scaling; at one GPU
+    # this is also the weak job).  The weak reading (4096 per GPU) and BASELINE configs[3] (65 536 in total) are timed below.
+    job = Job(args, args.offspring_per_gpu, world)
     job.reset()
     job.generations(preroll)                                   # clock ramp; a generation is ~0.25 ms
     job.reset()                                                # the measured run starts from the zero network
@@ -401,34 +403,36 @@ def run_rank(args):
     c0 = exchange_counts(job)
     times = timed_blocks(job, args.steps, max(args.blocks, 1), barrier, dist, world)
     c1 = exchange_counts(job)
-    weak = summarise(job, args.steps, times)
+    head = summarise(job, args.steps, times)
     if c0 is not None and c1 is not None:
         # what carried the two exchanges of a generation during the timed blocks: launches of ses_allgather_fitness / exchanges the
         # kernels did themselves with granules (the fitness inside ses_run_generations above 8192 rows, the chunk partials)
         gens = args.steps * max(args.blocks, 1)
-        weak["exchanges_per_generation"] = {"allgather_launches": (c1[0] - c0[0]) / gens, "granule_exchanges": (c1[1] - c0[1]) / gens}
+        head["exchanges_per_generation"] = {"allgather_launches": (c1[0] - c0[0]) / gens, "granule_exchanges": (c1[1] - c0[1]) / gens}
     from ses.parallel import comm_info, comm_transport
     comm_rank, comm_world, rccl_version = comm_info(job.loop.dev)
     transport = comm_transport(job.loop.dev, -(-job.n_global // world)) if world > 1 else "none"
-    weak.update(job.phases())
-    weak["rccl_ranks"] = comm_world
-    weak["allgather_transport"] = transport
+    head.update(job.phases())
+    head["rccl_ranks"] = comm_world
+    head["allgather_transport"] = transport
 
     result = {
-        "metric": METRIC, "value": weak["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": weak["ms_per_step"], "ms_per_step_min": weak["ms_per_step_min"],
-        "ms_per_step_max": weak["ms_per_step_max"], "blocks": weak["blocks"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "metric": METRIC, "value": head["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "ms_per_step_min": head["ms_per_step_min"],
+        "ms_per_step_max": head["ms_per_step_max"], "blocks": head["blocks"],
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("POMDP CartPole-v1 openai_es GRU(4-32-GRU32-2, P=6562)" if args.gru else
                                 "CartPole-v1 openai_es MLP(4-32-2, P=226)") + ", fixed-length episodes, termination masked",
                    "timed_call": ("ESLoop.generations(steps): the product loop's own enqueue path -- ses_run_generations in chunks of <= 32 "
                                   "generations, the fitness all-gather issued by the C loop" if job.loop.batched_generations or
                                   getattr(job.loop, "_bench_batch", None) else
                                   "ESLoop.generation() x steps (the product loop's per-generation method), openai_es strategy object"),
-                   "value_is": ("whole-job env-steps/s of the WEAK leg: 4096 offspring per GPU, i.e. offspring_total = 4096 x n_gpus; the "
-                                "literal reading of the metric (4096 offspring in total, sharded) is strong_4096_total.value, and "
-                                "BASELINE configs[3] is c4_65536_total.value -- at n_gpus = 1 the first two coincide"),
-                   "offspring_per_gpu": args.offspring_per_gpu, "offspring_total": job.n_global, "eval_ep_num": E,
+                   "value_is": ("whole-job env-steps/s of the metric AS WRITTEN: 4096 offspring in total, sharded over n_gpus (strong "
+                                "scaling: per-GPU work shrinks as n_gpus grows; a 0.2 ms generation of 500 dependent env steps cannot "
+                                "shrink much).  Beside it: weak_4096_per_gpu.value (4096 offspring PER GPU, offspring_total = 4096 x "
+                                "n_gpus) and c4_65536_total.value (BASELINE configs[3]); each with a *_rccl twin timed with the "
+                                "exchanges forced onto ncclAllGather.  At n_gpus = 1 the first two coincide"),
+                   "offspring_per_gpu": -(-job.n_global // world), "offspring_total": job.n_global, "eval_ep_num": E,
                    "max_step": T, "env_steps_per_generation": job.steps_per_generation(),
                    "noise": "rocRAND philox4x32_10", "preroll_generations": preroll,
                    "parallelism": (f"population on {world} GPU(s)" if world == 1 else
@@ -437,17 +441,38 @@ def run_rank(args):
                                     "rccl": f"ncclAllGather, RCCL {rccl_version}, {comm_world} rank(s)",
                                     "torch": f"FALLBACK torch.distributed/{backend} (no library transport could be set up)"}[transport])},
         "parity": PARITY_NOTE,
-        "weak_4096_per_gpu": weak,
+        "strong_4096_total": head,
     }
+    if world == 1:
+        result["weak_4096_per_gpu"] = dict(head, note="same job as strong_4096_total at 1 GPU")
+
+    def rccl_twin(j, steps_, blocks_):
+        """The same job with every exchange of a generation forced onto RCCL (ncclAllGather on the handle's stream: the fitness
+        shards, and the chunk partials of the shard form of the tail) through the same ESLoop.generations -> ses_run_generations
+        path.  "absent" where no communicator spans the ranks (rigs whose ranks share a GPU)."""
+        owner = getattr(j.loop.dev, "_comm_owner", None)
+        if world == 1 or owner is None or owner.comm_route()[2] != world:
+            return "absent"
+        try:
+            owner.set_tuning("comm_force_rccl", 1)
+            j.generations(30)
+            rec = summarise(j, steps_, timed_blocks(j, steps_, blocks_, barrier, dist, world))
+            rec.update(j.phases())
+            rec["allgather_transport"] = "rccl (forced)"
+            rec["rccl_ranks"] = comm_info(j.loop.dev)[1]
+            return rec
+        except Exception as exc:
+            return {"error": repr(exc)}
+        finally:
+            owner.set_tuning("comm_force_rccl", 0)
+
+    result["strong_4096_total_rccl"] = rccl_twin(job, min(args.steps, 100), 7)
 
     # ---- the two other readings of the metric ------------------------------------------------------------------------
     if not args.no_extras:
         x_steps, x_blocks = min(args.steps, 100), 7
-        for key, n_total in (("strong_4096_total", 4096), ("c4_65536_total", 65536)):
-            if key in os.environ.get("SES_BENCH_SKIP", ""):
-                continue
-            if key == "strong_4096_total" and world == 1 and args.offspring_per_gpu == 4096:
-                result[key] = dict(weak, note="same job as weak_4096_per_gpu at 1 GPU")
+        for key, n_total in (("weak_4096_per_gpu", args.offspring_per_gpu * world), ("c4_65536_total", 65536)):
+            if key in os.environ.get("SES_BENCH_SKIP", "") or key in result:
                 continue
             try:
                 j = Job(args, n_total, world)
@@ -464,9 +489,29 @@ def run_rank(args):
                 rec["rccl_ranks"] = comm_info(j.loop.dev)[1]
                 rec["allgather_transport"] = comm_transport(j.loop.dev, -(-n_total // world)) if world > 1 else "none"
                 result[key] = rec
+                result[key + "_rccl"] = rccl_twin(j, x_steps, x_blocks)
                 del j
             except Exception as exc:                                 # the headline line must still be printed
                 result[key] = {"error": repr(exc)}
+
+        # ---- the same job with ONE episode per offspring (--eval-ep-num 1; the reference's default is 5, run_es.py:33-38) ----
+        if E != 1 and "e1" not in os.environ.get("SES_BENCH_SKIP", ""):
+            try:
+                a1 = argparse.Namespace(**vars(args))
+                a1.eval_ep_num = 1
+                j = Job(a1, args.offspring_per_gpu * world, world)
+                j.reset()
+                j.generations(60)
+                rec = summarise(j, x_steps, timed_blocks(j, x_steps, x_blocks, barrier, dist, world))
+                rec.update(j.phases())
+                rec["eval_ep_num"] = 1
+                rec["env_steps_per_generation"] = j.steps_per_generation()
+                rec["note"] = ("4096 envs per GPU instead of 20 480: a fifth of the rollout work against the same per-generation tail "
+                               "(rank, gradient, update, perturbation), so fewer env-steps/s than the E = 5 line of record")
+                result["e1"] = rec
+                del j
+            except Exception as exc:
+                result["e1"] = {"error": repr(exc)}
 
         # ---- the loop a user runs: ESLoop.run() with its prints and metrics.jsonl ------------------------------------
         # Two fresh loops of different length; the per-generation figure is the difference quotient, so that what a
@@ -575,6 +620,25 @@ def run_rank(args):
             else:
                 result["rollout_kernel"]["valu_note"] = (f"{os.path.relpath(sq, ROOT)} was collected on different machine "
                                                          "code of this kernel: not attached")
+            # the same duration against the serial-issue MODEL of the kernel's own instruction mix (tools/issue_model.py: every
+            # VALU instruction of the two loop bodies priced at its measured issue cadence): SIMD cycles the loops need over the
+            # SIMD cycles the kernel had.  valu_issue_frac above prices every instruction at the nominal 2 cycles.
+            models = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_issue_model.json"))
+            if models and not args.gru:
+                im = json.load(open(os.path.join(ROOT, "profiles", models[-1])))
+                if im.get("kernel_code_sha256") and im["kernel_code_sha256"] == now:
+                    need = sum(v["waves"] * v["cycles"] for v in im["issue_cycles_per_step"].values()) * T
+                    have = 1024 * roll_ms * 1e-3 * im["clock_ghz_under_load"] * 1e9
+                    result["rollout_kernel"].update({
+                        "valu_issue_model_frac": need / have,
+                        "valu_issue_model": {k: v["cycles"] for k, v in im["issue_cycles_per_step"].items()},
+                        "valu_issue_model_source": os.path.join("profiles", models[-1]),
+                        "valu_issue_model_note": "SIMD cycles per env step of a light + a heavy wave if every VALU instruction issued alone "
+                                                 "at its measured cadence (2 / 4 / 8 cycles), x steps, over duration x clock; the duration "
+                                                 "includes the ~4.4 us episode-mean kernel"})
+                else:
+                    result["rollout_kernel"]["valu_issue_model_note"] = (f"profiles/{models[-1]} prices different machine code of this "
+                                                                         "kernel (rerun tools/issue_model.py): not attached")
         # BASELINE.json configs[2]: LunarLanderContinuous-v2 POMDP, GRU policy, 4096 offspring (conf/lunarlander_openai.yaml):
         # one rollout of first-generation policies (sigma = init_sigma around the zero network), episodic
         if not args.no_extras and not args.gru:
@@ -734,6 +798,11 @@ def run_rank(args):
                                                   note="100 back-to-back ses_allgather_fitness per transport, max over ranks, us per exchange")
         except Exception as exc:
             result["allgather_microbench"] = {"error": repr(exc)}
+        finally:                                                       # whatever happened above, the transport is left as it was found
+            owner = getattr(job.loop.dev, "_comm_owner", None)
+            if owner is not None:
+                owner.set_tuning("comm_force_rccl", 0)
+                owner.set_tuning("comm_granule_allgather", 0)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -423,9 +423,17 @@ int ses_comm_p2p_attach(ses_handle *h, const void *handles);
  * enabled peer access between, and every handle must detach before any of them is destroyed.  An exchange kernel WAITS for
  * kernels of its peers: each handle needs not just a stream but a HARDWARE QUEUE of its own.  Handles on different devices
  * have that by construction; for handles that share a device it is the runtime's choice (GPU_MAX_HW_QUEUES, default 4, and
- * the order in which streams were created) -- two streams on one queue are a dead wait until the time-out -- so that use is
- * for test rigs (tests/test_gpu_sharded_tail.py: one process, GPU_MAX_HW_QUEUES = ranks + 1, streams created once). */
+ * the order in which streams were created) -- two streams on one queue are a dead wait until the time-out -- unless the
+ * streams come from ses_stream_create_exclusive below (tests/test_gpu_sharded_tail.py: one process, a stream per rank). */
 int ses_comm_p2p_attach_local(ses_handle *h, ses_handle *const *peers);
+/* A HIP stream with a hardware queue of its OWN on `device`, for handles that share a device and wait for each other's kernels
+ * (above).  The runtime pools the queues of ordinary streams -- GPU_MAX_HW_QUEUES of them per priority, shared round-robin --
+ * but a stream created with a CU mask (hipExtStreamCreateWithCUMask) never enters the pool: it always gets a queue created for
+ * it.  The mask given here names every CU of the device, so it restricts nothing.  *stream is a hipStream_t for ses_create
+ * (and torch.cuda.ExternalStream); ses_stream_destroy ends it.  This is what makes the in-process many-rank rig deterministic
+ * (tests/test_gpu_sharded_tail.py); one process per GPU -- the product's way to run -- never needs it. */
+int ses_stream_create_exclusive(int32_t device, void **stream);
+int ses_stream_destroy(void *stream);
 int ses_comm_p2p_info(ses_handle *h, int32_t *world, int32_t *max_per_rank, int32_t *exchanges);
 /* exchanges issued over the attached transport so far, by kind: with sequence words (ses_allgather_fitness) / as granules (the
  * exchanges kernels do themselves: chunk partials and, inside ses_run_generations, the fitness; the granule all-gather) */

@@ -440,6 +440,32 @@ int ses_comm_p2p_reset_status(ses_handle *h)
     return SES_OK;
 }
 
+int ses_stream_create_exclusive(int32_t device, void **stream)
+{
+    SES_REQUIRE(stream, "ses_stream_create_exclusive: null argument");
+    int ndev = 0;
+    SES_HIP_TRY(hipGetDeviceCount(&ndev));
+    SES_REQUIRE(device >= 0 && device < ndev, "ses_stream_create_exclusive: device %d not in [0,%d)", device, ndev);
+    SES_HIP_TRY(hipSetDevice(device));
+    int cus = 0;
+    SES_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    SES_REQUIRE(cus >= 1 && cus <= 1024, "ses_stream_create_exclusive: %d compute units?", cus);
+    uint32_t mask[32];
+    const int words = (cus + 31) / 32;
+    for (int w = 0; w < words; ++w) mask[w] = (w + 1) * 32 <= cus ? 0xFFFFFFFFu : ((1u << (cus - w * 32)) - 1u);
+    hipStream_t s = nullptr;
+    SES_HIP_TRY(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
+    *stream = (void *)s;
+    return SES_OK;
+}
+
+int ses_stream_destroy(void *stream)
+{
+    SES_REQUIRE(stream, "ses_stream_destroy: null stream");
+    SES_HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return SES_OK;
+}
+
 int ses_comm_p2p_detach(ses_handle *h)
 {
     SES_REQUIRE(h, "ses_comm_p2p_detach: null handle");

@@ -55,7 +55,7 @@ int ses_run_generations(ses_handle *h, ses_gen_state *st, int32_t k, float *best
     // rank's mailbox, the rank kernel of the tail polls the tiles it sorts (k_fitness_mean_granules, k_rank_sort_search<true>)
     // (up to 8192 rows the counting rank polls them, k_rank_count_granules: also where the tail runs replicated, e.g. 4096 rows in
     //  total over 8 ranks)
-    const bool fused_fit = multi && openai && openai_fused_fitness_ok(h, n, st->per_rank, sharded_tail ? n_loc : n) == 1;
+    const bool fused_fit = multi && openai && openai_fused_fitness_ok(h, n, st->per_rank, sharded_tail ? st->per_rank : n) == 1;   // (the slot size, not this rank's rows: a ragged last rank must decide like the others)
     // one GPU, openai_es, counting rank (up to 8192 rows): the episode mean is formed inside the rank count (k_rank_count_episodes)
     // -- ses_rollout leaves the per-episode returns, no mean kernel between the rollout and the tail
     const bool fused_mean = !multi && openai && h->tune_fused_mean && n <= 8192;

@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 from ses import HipES, MODE_EPISODIC, MODE_FIXED_LENGTH
-from ses.parallel import attach_comm, comm_failed, comm_keep_going, comm_recover
+from ses.parallel import all_ranks, attach_comm, comm_failed, comm_keep_going, comm_recover
 
 from .abstracts import BaseESLoop
 
@@ -368,6 +368,19 @@ class ESLoop(BaseESLoop):
         finally:
             comm_keep_going(self.dev, False)
 
+    def _generation_batch(self, strategy, offsprings):
+        """The device-side loop for this run, or None.  COLLECTIVE on a sharded run: eligible() looks at process-local state
+        (a hooked method on one rank only, SES_BATCH_GENERATIONS in one rank's environment, this rank's transports), and the
+        two forms issue DIFFERENT exchanges on the peer-store transport -- the C loop fuses the fitness exchange into a
+        granule exchange, the per-generation path uses the flag-based all-gather plus one granule exchange -- so ranks that
+        decided differently would wait for each other's exchanges until the time-out.  The ranks therefore take the MIN of
+        their answers over the control plane: one rank that cannot, nobody does."""
+        ok = _GenerationBatch.eligible(self, strategy, offsprings)
+        shard = offsprings.shard
+        if shard.world > 1:
+            ok = all_ranks(ok, self.dev.device, shard.group)
+        return _GenerationBatch(self, strategy, offsprings) if ok else None
+
     def _run_segments(self, strategy, offsprings, rank0, guarded):
         """The run as segments between boundaries -- checkpoint generations, the end, and for a guarded (multi-GPU) run at
         least every comm_check_period generations.  Inside a segment the generations go to the device k at a time through
@@ -378,21 +391,36 @@ class ESLoop(BaseESLoop):
         the last boundary and, if so, rolls back to it."""
         period = self.save_model_period
         snap = (0, strategy.snapshot(offsprings), len(self.history), list(self.ep5_rewards)) if guarded else None
-        batch = _GenerationBatch(self, strategy, offsprings) if _GenerationBatch.eligible(self, strategy, offsprings) else None
+        batch = self._generation_batch(strategy, offsprings)
         self._last_report = 0.0
-        ep_num = 0
         # The device-side loop does not drain its queue at a checkpoint generation: the elite's parameters are copied to pinned
         # host memory by a copy enqueued behind that generation (snapshot_elite) and the file is written later -- an unguarded run
         # writes it when the chunk is reported (one chunk late, like the prints, while the device works on the next chunk); a
         # guarded run when the ranks have agreed, at the next boundary, that no exchange failed up to there (no checkpoint is
         # ever written from a generation that consumed a NaN shard), so its files appear up to comm_check_period generations
         # late.  (Draining cost conf/cartpole_openai.yaml, a checkpoint every 10 generations, 40 of its 280 us per generation.)
-        chunk, ckpts = None, []
+        ckpts = []
         drain = os.environ.get("SES_DRAIN_CHECKPOINTS", "0") == "1"       # (A/B runs of the old behaviour: drain at every checkpoint)
 
         def next_checkpoint(ep):
             return (ep // period + 1) * period
 
+        self._reported_upto = 0
+        try:
+            return self._segments_loop(strategy, offsprings, rank0, guarded, period, snap, batch, ckpts, drain, next_checkpoint)
+        finally:
+            # Whatever ends the loop early (a failed launch, KeyboardInterrupt): the elite snapshots of generations that were
+            # already REPORTED are good -- the reference would have written them synchronously (loop.py:101-104) -- and only wait
+            # for their file.  (A guarded run writes at its agreement points; what is still waiting there is not known good.)
+            if not guarded and ckpts and rank0:
+                try:
+                    self._write_checkpoints(ckpts, self._reported_upto, strategy)
+                except Exception:
+                    pass
+
+    def _segments_loop(self, strategy, offsprings, rank0, guarded, period, snap, batch, ckpts, drain, next_checkpoint):
+        chunk = None
+        ep_num = 0
         while ep_num < self.generation_num:
             # where the queue is drained: the end; a guarded run's agreement points; per-generation segments and
             # SES_DRAIN_CHECKPOINTS=1 also at every checkpoint generation (their checkpoints are written synchronously)
@@ -442,8 +470,7 @@ class ESLoop(BaseESLoop):
                     if rank0 and self._metrics is not None:      # the rows of the replayed generations above this one are void
                         self._metrics.write(json.dumps({"rollback_to": ep_num}) + "\n")
                     # the transport has changed: the device-side loop continues only if a library transport is left
-                    batch = (_GenerationBatch(self, strategy, offsprings)
-                             if _GenerationBatch.eligible(self, strategy, offsprings) else None)
+                    batch = self._generation_batch(strategy, offsprings)
                     continue
                 self._write_checkpoints(ckpts, ep_num, strategy)         # every rank's exchanges up to here were good
                 snap = (ep_num, strategy.snapshot(offsprings), len(self.history), list(self.ep5_rewards))
@@ -467,6 +494,7 @@ class ESLoop(BaseESLoop):
         first, k, best, stamps, sigmas, t0 = chunk
         for j in range(k):
             self._report(first + j, PendingReward(best[j:j + 1]), sigmas[j], stamps[j], t0, True, rank0)
+        self._reported_upto = first + k - 1
 
     def generations(self, offsprings, k):
         """Enqueue k generations without waiting for the GPU and without the per-generation bookkeeping of run(): through
@@ -475,9 +503,8 @@ class ESLoop(BaseESLoop):
         strategy = self.offspring_strategy
         batch = getattr(self, "_bench_batch", None)
         if batch is None or batch[0] is not offsprings:
-            batch = None
-            if _GenerationBatch.eligible(self, strategy, offsprings):
-                batch = (offsprings, _GenerationBatch(self, strategy, offsprings))
+            made = self._generation_batch(strategy, offsprings)          # (collective on a sharded run)
+            batch = (offsprings, made) if made is not None else None
         if batch is None:
             for _ in range(k):
                 offsprings, _best, _sigma, _stamp = self.generation(offsprings)

@@ -126,8 +126,10 @@ class _DeviceStrategy(BaseOffspringStrategy):
         self.network = network
         network.zero_init()           # every strategy starts from the zero network (offspring_strategies.py:83,200,348)
         self.dev = HipES(None, network.num_state, network.num_action, network.discrete_action, network.use_gru)
-        attach_comm(self.dev)         # multi-GPU: the shard form of the openai_es tail exchanges its chunk partials (collective
-        self.P = self.dev.P           # only the first time a process attaches; ESLoop has done that)
+        # multi-GPU: the shard form of the openai_es tail exchanges its chunk partials over the transports ESLoop attached
+        # (attach_comm there is the collective one).  Here: reuse only -- a strategy built on some ranks never starts a rendezvous
+        attach_comm(self.dev, create=False)
+        self.P = self.dev.P
         self._ring = _ReadbackRing(self.dev.device)
         self._shards = {}
 

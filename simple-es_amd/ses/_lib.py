@@ -113,6 +113,8 @@ SIGNATURES = {
     "ses_comm_p2p_export": [_vp, _i32, _i32, _i32, _vp],
     "ses_comm_p2p_attach": [_vp, _vp],
     "ses_comm_p2p_attach_local": [_vp, _vp],
+    "ses_stream_create_exclusive": [_i32, _vp],
+    "ses_stream_destroy": [_vp],
     "ses_comm_p2p_info": [_vp, _vp, _vp, _vp],
     "ses_comm_p2p_counts": [_vp, _vp, _vp],
     "ses_comm_p2p_status": [_vp, _vp],

@@ -43,6 +43,18 @@ def _stdout_to_stderr():
         os.close(saved)
 
 
+def exclusive_stream(device=None):
+    """A torch stream with a hardware queue of its own (ses_stream_create_exclusive): for HipES handles that share a device and
+    exchange over the peer-store transport from ONE process -- their kernels wait for each other, so two of them must never sit
+    behind one another on one queue.  The stream lives as long as the process (rigs create a handful)."""
+    if not torch.cuda.is_available():
+        raise SesError("no HIP device visible to torch")
+    device = torch.cuda.current_device() if device is None else int(device)
+    raw = ctypes.c_void_p()
+    check(_lib.load().ses_stream_create_exclusive(device, ctypes.byref(raw)), "ses_stream_create_exclusive")
+    return torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", device))
+
+
 class HipES:
     """One handle = one (env, network shape, device, stream).  Mirrors the constructor arguments of
     the reference's builder.build_env / build_network (builder.py:10-24)."""

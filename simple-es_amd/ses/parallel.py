@@ -36,6 +36,13 @@ def _cpu_group_ok(ok, device, group):
     return int(flag.item()) == 1
 
 
+def all_ranks(ok, device, group=None):
+    """COLLECTIVE: True iff `ok` is true on every rank of the group (world 1 / no process group: `ok` itself)."""
+    if not _dist_on() or dist.get_world_size(group) == 1:
+        return bool(ok)
+    return _cpu_group_ok(ok, device, group)
+
+
 def _attach_p2p(owner, rank, world, group):
     """Peer-store transport (ses_comm_p2p_*): every rank exports a mailbox, the handles travel over the control plane,
     every rank maps the others; then ONE exchange of a known pattern is checked on every rank.  All ranks must be on one
@@ -135,7 +142,7 @@ def _attach_rccl(owner, rank, world, group):
     return agreed
 
 
-def attach_comm(dev, group=None, allow_single=False):
+def attach_comm(dev, group=None, allow_single=False, create=True):
     """Give the HipES handle `dev` access to the library's all-gather over the process group (no-op at world 1).
     Collective: every rank of the group must call it.  One dedicated long-lived handle per process and group, bound to
     the same stream, owns the transports and is shared by every loop of the process (bench.py builds several):
@@ -143,12 +150,17 @@ def attach_comm(dev, group=None, allow_single=False):
         single-GPU tests drive it); verified by one checked exchange before it is used;
       * an RCCL communicator when the backend is "nccl" (shards beyond the mailbox size, or no peer stores).
     If neither can be set up on ALL ranks, every rank falls back to torch.distributed's all-gather, which is reported
-    (comm_transport() == "torch") instead of failing the run.  Returns True when the library carries the data path."""
+    (comm_transport() == "torch") instead of failing the run.  Returns True when the library carries the data path.
+    create=False: NOT collective -- bind `dev` to the owner this process already has for the group, or to none (a strategy
+    object built on a subset of the ranks, e.g. a rank-0 evaluation script under torchrun, must not start a rendezvous)."""
     if not _dist_on() or (dist.get_world_size(group) == 1 and not allow_single):   # allow_single: the 1-GPU test of this path
         return False
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     key = (id(group) if group is not None else 0, world)
     owner = _COMM.get(key)
+    if owner is None and not create:
+        dev._comm_owner = None
+        return False
     if owner is None:
         from .device import HipES
         owner = HipES(None, dev.S, dev.A, dev.discrete, dev.gru, device=dev.device.index)

@@ -148,6 +148,8 @@ FREEZE_WORKER = textwrap.dedent("""
     from learning_strategies.evolution.loop import ESLoop
     from ses.parallel import comm_transport
     ESLoop.comm_check_period = 4
+    batched = len(sys.argv) > 2 and sys.argv[2] == "batched"
+    from learning_strategies.evolution import loop as loop_module
     os.chdir(out_dir)
     for name, n in (("openai_es", 203), ("simple_evolution", 96), ("simple_genetic", 120)):
         cfg = {"env": {"name": "CartPole-v1", "max_step": 100, "pomdp": False, "seed": 3},
@@ -164,9 +166,33 @@ FREEZE_WORKER = textwrap.dedent("""
                 torch.cuda.synchronize()
                 time.sleep(1.5)                      # this rank freezes for five time-outs of its peer
             return _o(pop)
-        loop.generation = generation
-        with contextlib.redirect_stdout(io.StringIO()):
-            loop.run()
+        orig_run = loop_module._GenerationBatch.run
+        chunks = [0]
+        def run_chunk(self, k, _o=orig_run):
+            # the device-side loop (ses_run_generations): the stall sits between two chunks, on the CLASS -- a hook on the loop
+            # object would put run() back on the per-generation path
+            chunks[0] += 1
+            if world > 1 and rank == 1 and chunks[0] == 2 and name == "openai_es":
+                torch.cuda.synchronize()
+                time.sleep(1.5)
+            return _o(self, k)
+        orig_gen = ESLoop.generation
+        def counted(self, pop, _o=orig_gen):       # on the class: the per-generation calls of the replay are counted, run() stays eligible
+            calls[0] += 1
+            return _o(self, pop)
+        if batched:
+            loop_module._GenerationBatch.run = run_chunk
+            ESLoop.generation = counted
+        else:
+            loop.generation = generation
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                loop.run()
+        finally:
+            loop_module._GenerationBatch.run = orig_run
+            ESLoop.generation = orig_gen
+        if batched:
+            calls[0] += loop.batched_generations
         after = comm_transport(loop.dev) if world > 1 else "none"
         elite = loop.offspring_strategy.get_elite_model().flat()
         saved = sorted(os.listdir(os.path.join(loop.save_dir, "saved_models"))) if loop.save_dir else []
@@ -178,19 +204,22 @@ FREEZE_WORKER = textwrap.dedent("""
 """)
 
 
-def test_a_frozen_rank_costs_a_rollback_not_the_run(tmp_path):
-    """One rank stalls for 1.5 s while its peer's exchanges give up after 0.3 s (SES_COMM_P2P_TIMEOUT_MS): the run is not
+@pytest.mark.parametrize("mode", ["stepwise", "batched"])
+def test_a_frozen_rank_costs_a_rollback_not_the_run(tmp_path, mode):
+    """(batched: the same through the device-side loop -- the stall between two ses_run_generations chunks, the time-out inside the
+    kernels that poll the granules, the rollback out of a batched segment, the deferred checkpoints.)
+    One rank stalls for 1.5 s while its peer's exchanges give up after 0.3 s (SES_COMM_P2P_TIMEOUT_MS): the run is not
     killed and nothing diverges silently -- at the next boundary the ranks agree that an exchange failed, drop the
     peer-store transport (torch.distributed carries the all-gather from there on this rig), roll back to the last
     boundary and replay.  History, sigma trace and final parent equal the undisturbed one-rank run bit for bit, and
     the strategies that ran afterwards (no transport left) are equal too."""
     script = tmp_path / "fz.py"
     script.write_text(FREEZE_WORKER % (ROOT, SRC))
-    one = subprocess.run([sys.executable, str(script), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    one = subprocess.run([sys.executable, str(script), str(tmp_path), mode], capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stdout + one.stderr
     env = {**os.environ, "SES_COMM_P2P": "1", "SES_COMM_P2P_TIMEOUT_MS": "300"}
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script), str(tmp_path)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script), str(tmp_path), mode],
                          capture_output=True, text=True, timeout=900, env=env)
     assert two.returncode == 0, two.stdout + two.stderr
     assert "timed out" in two.stderr

@@ -1,5 +1,5 @@
 """The shard form of the openai_es tail (ses_openai_generation_sharded) at the world sizes the 1-GPU rig cannot form with
-processes: 8 and 16 ranks as HANDLES of one process, each on a stream of its own, their mailboxes attached directly
+processes: 8 and 16 ranks as HANDLES of one process, each on a stream with a hardware queue of its own, their mailboxes attached directly
 (ses_comm_p2p_attach_local) -- the peer-store protocol, the kernels and the layouts are those of one process per GPU.
 Every rank ranks and accumulates its own rows only; parent, Adam moments, best reward and the next population's rows must
 equal the replicated ses_openai_generation bit for bit (offspring_strategies.py:380-419 + :284-328 of the reference,
@@ -18,12 +18,13 @@ SRC = os.path.join(ROOT, "simple-es_amd")
 WORKER = textwrap.dedent("""
     import os, sys
     world, per, missing, P_gru, granules = (int(v) for v in sys.argv[1:6])
-    os.environ["GPU_MAX_HW_QUEUES"] = str(max(world + 1, 4))      # a hardware queue per stream: an exchange kernel waits for its peers'
     import numpy as np, torch
     sys.path[:0] = [%r, %r]
-    from ses import HipES
+    from ses import HipES, exclusive_stream
     n = world * per - missing
-    streams = [torch.cuda.Stream() for _ in range(world)]
+    # a hardware queue per rank, by construction (ses_stream_create_exclusive: streams that never enter the runtime's queue
+    # pool): an exchange kernel waits for kernels of its peers' streams, so none of them may queue up behind another
+    streams = [exclusive_stream() for _ in range(world)]
     ranks = [HipES(None, 4, 2, True, bool(P_gru), stream=streams[r]) for r in range(world)]
     ref = HipES(None, 4, 2, True, bool(P_gru))
     P = ref.P
@@ -95,11 +96,5 @@ def test_sharded_tail_equals_replicated_tail_bitwise(tmp_path, world, per, missi
     script.write_text(WORKER % (ROOT, SRC))
     cmd = ["timeout", "-k", "10", "300", sys.executable, str(script), str(world), str(per), str(missing), str(gru), str(granules)]
     run = subprocess.run(cmd, capture_output=True, text=True, timeout=400)
-    if run.returncode != 0 and "an exchange timed out" in run.stderr:
-        # Ranks as handles of ONE process on ONE device are a rig: an exchange kernel waits for kernels of its peers' streams, and
-        # which hardware queue a stream lands on is the runtime's choice (two on one queue: a dead wait until the 5 s time-out --
-        # include/ses.h, ses_comm_p2p_attach_local).  A time-out here says nothing about the arithmetic under test: once more.
-        print("in-process rig: an exchange timed out (hardware-queue placement), running the case once more")
-        run = subprocess.run(cmd, capture_output=True, text=True, timeout=400)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
     assert run.stdout.strip().endswith(f"ok {world} {per} {world * per - missing}")

@@ -155,6 +155,14 @@ def test_sweep_files_keep_reference_format_and_points_are_reproducible():
     grid = list(sweep_main.trial_points(spec, None, random.Random(0)))
     assert len(grid) == 6 and {(p["init_sigma"], p["elite_num"]) for p in grid} == {(s, k) for s in (0.5, 1.0, 2.0) for k in (2, 4)}
     assert all(p["cfg_path"] == "conf/cartpole.yaml" and p["generation_num"] == 20 for p in grid)
+    # the reference ships two sweep files (sweep_config/bipedal_genetic.yaml, lunarlander_openaies.yaml): both are here
+    assert {"bipedal_genetic.yaml", "lunarlander_openaies.yaml"} <= set(os.listdir(os.path.join(SRC, "sweep_config")))
+    spec = yaml.load(open(os.path.join(SRC, "sweep_config", "bipedal_genetic.yaml")), Loader=yaml.FullLoader)
+    pts = list(sweep_main.trial_points(spec, 7, random.Random(1)))
+    assert len(pts) == 7 and pts == list(sweep_main.trial_points(spec, 7, random.Random(1)))
+    assert all(p["cfg_path"] == "conf/bipedalwalker.yaml" and p["generation_num"] == 300 and p["offspring_num"] == 96 and
+               p["elite_num"] in (5, 10, 15, 20) and 0.05 <= p["init_sigma"] <= 2.0 and p["sigma_decay"] in (0.999, 0.9999)
+               for p in pts)
     spec = yaml.load(open(os.path.join(SRC, "sweep_config", "cartpole_openaies.yaml")), Loader=yaml.FullLoader)
     a = list(sweep_main.trial_points(spec, 5, random.Random(3)))
     b = list(sweep_main.trial_points(spec, 5, random.Random(3)))

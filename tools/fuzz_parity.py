@@ -37,20 +37,20 @@ def sharded_tail_case(rng, force=None):
     """One random layout of the shard form of the openai_es tail (ses_openai_generation_sharded) against the replicated tail:
     2 ranks as handles of this process on streams of their own, shards of 1-5 chunks, a ragged last shard, every policy size, both
     rank paths (counting / sort + search) and both ways the chunk partials travel (granules / float all-gather).  Two ranks only:
-    an exchange kernel waits for kernels of its peer's stream, so every stream needs a hardware queue of its own, a process has four
-    by default, and five fuzz processes side by side already share the GPU's queue slots (larger worlds: tests/test_gpu_sharded_tail.py,
-    one process with GPU_MAX_HW_QUEUES = ranks + 1)."""
+    an exchange kernel waits for kernels of its peer's stream, so every stream needs a hardware queue of its own
+    (ses.exclusive_stream), and five fuzz processes side by side already share the GPU's queue slots (larger worlds:
+    tests/test_gpu_sharded_tail.py)."""
     world = 2
     per = 1024 * int(rng.choice([1, 1, 2, 3, 4, 5]))
     n = world * per - int(rng.randint(0, world))
     S, A, gru = [(4, 2, False), (8, 4, False), (24, 4, False), (12, 5, False), (4, 2, True)][int(rng.randint(0, 5))]
     if force:
         per, n, (S, A, gru) = force["per"], force["n"], force["shape"]
-    # the SAME two streams for every case of the process: which hardware queue a stream lands on is the runtime's choice, two
-    # streams that share one make an exchange kernel wait for a kernel queued behind it (observed with fresh streams per case: a
-    # dead wait every ~15 cases); a pair that works once works always
+    # streams with a hardware queue of their own (ses_stream_create_exclusive), created once per process: an exchange kernel
+    # waits for a kernel of its peer's stream, which must not be queued behind it
+    from ses import exclusive_stream
     while len(_RANK_STREAMS) < world:
-        _RANK_STREAMS.append(torch.cuda.Stream())
+        _RANK_STREAMS.append(exclusive_stream())
     streams = _RANK_STREAMS[:world]
     ranks = [HipES(None, S, A, A in (2, 5), gru, stream=streams[r]) for r in range(world)]
     ref = HipES(None, S, A, A in (2, 5), gru)

@@ -16,7 +16,7 @@ done
 for p in "${pids[@]}"; do wait $p; done
 # the in-process ranks of the `sharded_tail` kind spin on each other's kernels: they need their hardware queues RESIDENT, which five
 # processes side by side do not leave them (observed: dead waits until the time-out) -- one process, afterwards, a fifth of the time
-GPU_MAX_HW_QUEUES=8 python tools/fuzz_parity.py --cases 100000 --seed $((SEED0 + 5)) --time-limit $((LIMIT / 5)) --only sharded_tail > gpurun_out/fuzz_$((SEED0 + 5)).txt 2>&1
+python tools/fuzz_parity.py --cases 100000 --seed $((SEED0 + 5)) --time-limit $((LIMIT / 5)) --only sharded_tail > gpurun_out/fuzz_$((SEED0 + 5)).txt 2>&1
 python - <<'PY'
 import glob, json, os
 tot, cases, ok, secs = {}, 0, True, 0.0

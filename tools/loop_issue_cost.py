@@ -44,13 +44,13 @@ def cost(line):
     return op, 4
 
 
-def main():
-    text = open(sys.argv[1]).read().splitlines()
-    sym = sys.argv[2]
+def loops(text, sym, min_valu=40):
+    """[(mangled kernel name, [{label, valu, cycles, lds, salu, kinds}, ...])] for the first kernel whose mangled name contains
+    `sym`: every loop of at least min_valu VALU instructions whose back edge targets its own header."""
     start = next(i for i, l in enumerate(text) if re.match(r"^_Z\w*" + sym + r"\w*:", l))
     end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
-    print(text[start].split(":")[0])
     body = text[start:end]
+    out = []
     i = 0
     while i < len(body):
         m = re.match(r"^(\.LBB\d+_\d+):.*Loop Header", body[i])
@@ -76,10 +76,20 @@ def main():
                 valu += 1
                 cyc += c[1]
                 kinds[c[0]] = kinds.get(c[0], 0) + 1
-        if valu >= 40:
-            print(f"  loop {label}: {valu} VALU ({cyc} issue cycles = {cyc / valu:.2f} per instruction), {lds} LDS, {salu} SALU")
-            print("     " + ", ".join(f"{k} x{v}" for k, v in sorted(kinds.items(), key=lambda kv: -kv[1])))
+        if valu >= min_valu:
+            out.append({"label": label, "valu": valu, "cycles": cyc, "lds": lds, "salu": salu, "kinds": kinds})
         i = j + 1
+    return text[start].split(":")[0], out
+
+
+def main():
+    text = open(sys.argv[1]).read().splitlines()
+    name, found = loops(text, sys.argv[2])
+    print(name)
+    for lp in found:
+        print(f"  loop {lp['label']}: {lp['valu']} VALU ({lp['cycles']} issue cycles = {lp['cycles'] / lp['valu']:.2f} per instruction), "
+              f"{lp['lds']} LDS, {lp['salu']} SALU")
+        print("     " + ", ".join(f"{k} x{v}" for k, v in sorted(lp["kinds"].items(), key=lambda kv: -kv[1])))
 
 
 if __name__ == "__main__":
