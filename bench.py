@@ -677,10 +677,35 @@ def run_rank(args):
                     tl.append(e0.elapsed_time(e1))
                 _, _, stl = c3.rollout(thl, ini, want_episodes=True)
                 nl, msl = int(stl.sum().item()), statistics.median(tl)
+                # the floor of ANY schedule of this world step: the longest episode is a chain of dependent steps, and one env's
+                # step cannot take less than the latency of one world step on a wave that has its SIMD to itself.
+                # Measured here: 64 envs = one wave, in flight (gentle main engine), the step-wise entry back to back.
+                lone = HipES("LunarLanderContinuous-v2", 8, 4, False, False, pomdp=True, max_step=300, eval_ep_num=1)
+                st_l, _ = lone.env_reset(lone.init_states_uniform(3, 0, 0, 64)[:, 0].contiguous())
+                up = torch.zeros(64, 4, device="cuda")
+                up[:, 0] = 0.3
+                for _ in range(5):
+                    lone.env_step_generic(st_l, up)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(40):
+                    lone.env_step_generic(st_l, up)
+                e1.record()
+                e1.synchronize()
+                lone_us = e0.elapsed_time(e1) * 1e3 / 40
+                lone.close()
+                longest3, longestl = int(st3.max().item()), int(stl.max().item())
                 result["c3_lunarlander_pomdp_gru_4096"] = {
                     "rollout_ms": ms3, "env_steps": n3, "env_steps_per_s": n3 / (ms3 * 1e-3), "mean_episode_steps": n3 / (4096 * 5),
+                    "longest_episode_steps": longest3, "lone_wave_flight_step_us": lone_us,
+                    "floor_ms": longest3 * lone_us * 1e-3, "frac_of_floor": longest3 * lone_us * 1e-3 / ms3,
+                    "floor": "longest episode x the latency of one world step in flight on a wave alone on its SIMD (measured above with "
+                             "the step-wise entry, launch included; steps on the ground and the policy step cost more): no schedule of "
+                             "this world step finishes the population sooner, whatever its lane mapping",
                     "flying_policies": {"rollout_ms": msl, "env_steps": nl, "env_steps_per_s": nl / (msl * 1e-3),
-                                        "mean_episode_steps": nl / (4096 * 5),
+                                        "mean_episode_steps": nl / (4096 * 5), "longest_episode_steps": longestl,
+                                        "floor_ms": longestl * lone_us * 1e-3, "frac_of_floor": longestl * lone_us * 1e-3 / msl,
                                         "note": "same population, main-engine bias + 1.5: long flights, what trained policies cost"},
                     "env": "gym's lunar_lander.py restated on a Box2D-style world: 3 bodies, 2 revolute joints, 180 velocity + "
                            "<= 60 position iterations per step, time-of-impact sub-stepping against the terrain (parity with gym / Box2D unpinned; GPU == CPU build bit for bit)",

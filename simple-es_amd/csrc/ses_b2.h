@@ -116,6 +116,9 @@ struct JointRare {                   // the part of it that only a releasing lim
 // A pointer the compiler knows nothing about: what is stored through it stays in memory (device build: five registers
 // per joint less in the 180-iteration loop, which is what the last in-loop spills of the walker's solver were about).
 // development builds (-DSES_PHASE_TIMERS, tools/walker_phases.py) time the phases of a world step; nothing otherwise
+#ifndef B2_PHASE_ROWS
+#define B2_PHASE_ROWS(mask, iters)
+#endif
 #ifndef B2_PHASE
 #define B2_PHASE(k)
 #endif
@@ -891,6 +894,21 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
     for (int j = 0; j < D::NJ; ++j) joint_init<D>(body, joint, w.xf, j, jt[j], rare, dt);
 
     B2_PHASE(2);
+#ifdef SES_PHASE_TIMERS
+    {                                                          // development build: which contact rows this env's iterations execute
+        unsigned int rows = 0u;
+        B2_UNROLL
+        for (int b = 0; b < NBS; ++b) {
+            bool more = true;
+            B2_UNROLL
+            for (int r = 0; r < D::NSLOT; ++r) {
+                if (REPACK) more = more && ct[b][r].vcount != 0;
+                if (more && ct[b][r].vcount != 0) rows |= 1u << (b * D::NSLOT + r);
+            }
+        }
+        B2_PHASE_ROWS(any_contact ? rows : 0u, D::VEL_ITERS);
+    }
+#endif
     // (no wave-level votes anywhere in this file: a world only ever looks at its own state, so the code may run
     //  under any divergence; in flight the contact rows are skipped as a whole)
     const auto iterate = [&]() __attribute__((always_inline)) {
@@ -902,6 +920,9 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
         for (int it = 0; it < D::VEL_ITERS; ++it) {
             B2_UNROLL
             for (int j = 0; j < D::NJ; ++j) joint_solve_velocity<D>(body, joint, j, jt[j], rare);
+#ifdef SES_PHASE_SPLIT_VEL
+            B2_PHASE(3);                                       // (development build) the joints of this iteration
+#endif
             if (any_contact) {
                 B2_UNROLL
                 for (int b = D::FIRST_SOLVED; b < D::NB; ++b) {
@@ -913,6 +934,9 @@ B2_FN void world_solve(World<D> &w, Manifold (&mc)[D::NB - D::FIRST_SOLVED][D::N
                     }
                 }
             }
+#ifdef SES_PHASE_SPLIT_VEL
+            B2_PHASE(16);                                      // its contact rows
+#endif
         }
     } else {
         // Three plain loops instead of one with a test inside: the iterations before the check, the checked one, the rest.

@@ -28,10 +28,15 @@
 // development build: cycles between consecutive marks of a wave by the phase that ended at the mark, accumulated in LDS
 // (single-wave workgroups) and added to the totals when the wave ends (phase_flush) -- no memory operation at a mark
 namespace ses {
-static __device__ unsigned long long phase_total[16];
+// slots 0-15: phases (tools/walker_phases.py names them); 16: the contact rows of the velocity iterations when they are timed
+// apart from the joints (-DSES_PHASE_SPLIT_VEL: two more marks per iteration); 17-19: row census of the velocity iterations
+// (row slots the wave executed = union over its lanes per body / what a flat per-env list would execute = the largest lane
+// total / iterations counted), see phase_rows
+constexpr int PHASE_SLOTS = 24;
+static __device__ unsigned long long phase_total[PHASE_SLOTS];
 __device__ __forceinline__ unsigned long long *phase_lds()
 {
-    __shared__ unsigned long long a[4][17];                    // per wave of the workgroup (<= 4)
+    __shared__ unsigned long long a[4][PHASE_SLOTS + 1];       // per wave of the workgroup (<= 4)
     return a[(threadIdx.x >> 6) & 3];
 }
 __device__ __forceinline__ void phase_mark(int k)
@@ -40,18 +45,39 @@ __device__ __forceinline__ void phase_mark(int k)
     const unsigned long long now = __builtin_readcyclecounter();
     const unsigned long long m = __ballot(1);
     if ((int)__lane_id() == __ffsll((long long)m) - 1) {
-        if (k >= 0) a[k] += now - a[16];
-        else for (int i = 0; i < 16; ++i) a[i] = 0;
-        a[16] = now;
+        if (k >= 0) a[k] += now - a[PHASE_SLOTS];
+        else for (int i = 0; i < PHASE_SLOTS; ++i) a[i] = 0;
+        a[PHASE_SLOTS] = now;
+    }
+}
+// census of one world step's velocity iterations: `mask` has bit (body * slots + row) set for every contact row this lane's
+// env executes, the active lanes are the envs that step
+__device__ __forceinline__ void phase_rows(unsigned int mask, int iterations)
+{
+    unsigned long long *a = phase_lds();
+    const unsigned long long m = __ballot(1);
+    unsigned int uni = 0u;
+    for (int bit = 0; bit < 32; ++bit) uni |= __ballot((mask >> bit) & 1u) ? (1u << bit) : 0u;
+    const int mine = __popc(mask);
+    int most = 0;                                              // (lanes that are not stepping take no part: reduce over the ballot)
+    for (int l = 0; l < 64; ++l) {
+        const int v = __builtin_amdgcn_readlane(mine, l);
+        if ((m >> l) & 1ull) most = v > most ? v : most;
+    }
+    if ((int)__lane_id() == __ffsll((long long)m) - 1 && uni) {
+        a[17] += (unsigned long long)__popc(uni) * iterations;
+        a[18] += (unsigned long long)most * iterations;
+        a[19] += (unsigned long long)iterations;
     }
 }
 __device__ __forceinline__ void phase_flush()
 {
     unsigned long long *a = phase_lds();
-    if (__lane_id() < 16) atomicAdd(&phase_total[__lane_id()], a[__lane_id()]);
+    if (__lane_id() < PHASE_SLOTS) atomicAdd(&phase_total[__lane_id()], a[__lane_id()]);
 }
 }  // namespace ses
 #define B2_PHASE(k) ses::phase_mark(k)
+#define B2_PHASE_ROWS(mask, iters) ses::phase_rows((mask), (iters))
 #endif
 #define B2_F2U(f) ses::f2u(f)
 // two uniforms in (-1, 1) from the episode key and the step counter (oracle: ses_b2_oracle.cpp b2o_dispersion)

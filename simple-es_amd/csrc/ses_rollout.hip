@@ -1588,11 +1588,11 @@ int ses_policy_forward(ses_handle *h, const float *theta, const float *obs, floa
 
 #ifdef SES_PHASE_TIMERS
 // development build only (tools/walker_phases.py): the phase totals of ses_lander.h's phase_mark, read and optionally cleared
-extern "C" int ses_debug_phase_totals(unsigned long long *out16, int reset)
+extern "C" int ses_debug_phase_totals(unsigned long long *out24, int reset)
 {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ses::phase_total), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(ses::phase_total), ses::PHASE_SLOTS * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[16] = {};
+        unsigned long long z[ses::PHASE_SLOTS] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(ses::phase_total), z, sizeof z) != hipSuccess) return -1;
     }
     return 0;

@@ -24,12 +24,22 @@ theta = es.perturb(es.zeros(es.P), 0.5 if which == "c3" else 2.0, 0, 0, 0, n)
 init = es.init_states_uniform(0, 0, 0, n)
 fit = es.empty(n)
 lib = ctypes.CDLL(_lib.LIB_PATH)
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 24)()
 es.rollout(theta, init, fitness=fit); torch.cuda.synchronize()
 assert lib.ses_debug_phase_totals(buf, 1) == 0
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); es.rollout(theta, init, fitness=fit); e1.record(); e1.synchronize()
 assert lib.ses_debug_phase_totals(buf, 1) == 0
-tot = sum(buf[:16])
-print(json.dumps({"env": env, "offspring": n, "lanes_per_env": lpe, "envs_per_wave": epw, "rollout_ms_with_timers": round(e0.elapsed_time(e1), 2),
-                  "share": {NAMES[k]: round(buf[k] / tot, 4) for k in range(16)}}, indent=1))
+tot = sum(buf[:17])
+out = {"env": env, "offspring": n, "lanes_per_env": lpe, "envs_per_wave": epw, "rollout_ms_with_timers": round(e0.elapsed_time(e1), 2),
+       "share": {NAMES[k]: round(buf[k] / tot, 4) for k in range(16)}}
+if buf[16]:
+    # library built with -DSES_PHASE_SPLIT_VEL as well: the velocity iterations' joints ("velocity iterations" above) and contact rows apart
+    out["share"]["velocity iterations: joints only"] = out["share"].pop("velocity iterations")
+    out["share"]["velocity iterations: contact rows"] = round(buf[16] / tot, 4)
+if buf[19]:
+    # census over the world steps that had a contact: contact-row slots a wave executes per velocity iteration today (the union over its
+    # envs, body by body) and what a flat per-env list would execute (the largest total of any one env)
+    out["contact_rows_per_iteration"] = {"per_body_union": round(buf[17] / buf[19], 3), "flat_per_env_list": round(buf[18] / buf[19], 3),
+                                         "flat_over_union": round(buf[18] / buf[17], 3)}
+print(json.dumps(out, indent=1))
