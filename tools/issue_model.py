@@ -49,6 +49,7 @@ def main():
     lib = os.path.join(ROOT, "simple-es_amd", "libses_hip.so")
     model = {
         "kernel": name,
+        "kernel_match": "k_rollout_cartpole_mlp",
         "kernel_code_sha256": kernel_hash.hash_kernels(lib, "k_rollout_cartpole_mlp"),
         "workload": "4096 offspring x 5 episodes x 500 fixed-length steps: 1024 light waves (4 envs at 16 lanes per env) + 1024 heavy "
                     "waves (16 envs at 4 lanes per env), one of each per SIMD",
