@@ -678,7 +678,7 @@ def run_rank(args):
                 _, _, stl = c3.rollout(thl, ini, want_episodes=True)
                 nl, msl = int(stl.sum().item()), statistics.median(tl)
                 # the floor of ANY schedule of this world step: the longest episode is a chain of dependent steps, and one env's
-                # step cannot take less than the latency of one world step on a wave that has its SIMD to itself.
+                # step cannot take less than the latency of one world step on a wave that has its SIMD to itself (NOTES.md, "C3").
                 # Measured here: 64 envs = one wave, in flight (gentle main engine), the step-wise entry back to back.
                 lone = HipES("LunarLanderContinuous-v2", 8, 4, False, False, pomdp=True, max_step=300, eval_ep_num=1)
                 st_l, _ = lone.env_reset(lone.init_states_uniform(3, 0, 0, 64)[:, 0].contiguous())

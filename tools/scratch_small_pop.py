@@ -1,0 +1,22 @@
+import os, sys, json, statistics, torch
+sys.path[:0] = ["/root/repo", "/root/repo/simple-es_amd"]
+from ses import HipES, MODE_FIXED_LENGTH
+for n in (512, 1024, 2048, 4096):
+    row = {"offspring": n}
+    for lpe in (0, 4, 8, 16):
+        es = HipES("CartPole-v1", 4, 2, True, False, max_step=500, eval_ep_num=5, lanes_per_env=lpe)
+        theta = es.perturb(es.zeros(es.P), 0.1, 0, 0, 0, n)
+        init = es.init_states_uniform(0, 0, 0, 1, shared=True)[0].contiguous()
+        fit = es.empty(n)
+        for _ in range(30): es.rollout(theta, init, mode=MODE_FIXED_LENGTH, fitness=fit)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(9):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): es.rollout(theta, init, mode=MODE_FIXED_LENGTH, fitness=fit)
+            e1.record(); e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 100)
+        row[f"lpe{lpe}_us"] = round(statistics.median(ts), 1)
+        es.close()
+    print(json.dumps(row), flush=True)
