@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""The fused CartPole MLP rollout at the per-GPU populations of the strong-scaling line (4096 offspring in total over 1 / 2 / 4 / 8
+GPUs = 4096 / 2048 / 1024 / 512 per GPU), 5 episodes x 500 fixed-length steps, by lanes per env (0 = the library's choice)."""
 import os, sys, json, statistics, torch
-sys.path[:0] = ["/root/repo", "/root/repo/simple-es_amd"]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "simple-es_amd")]
 from ses import HipES, MODE_FIXED_LENGTH
 for n in (512, 1024, 2048, 4096):
     row = {"offspring": n}
