@@ -5,7 +5,7 @@
 # lines, loop timings.   usage: tools/gpu_final_round.sh [round tag = r03] [fuzz seconds per process = 240]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-TAG=${1:-r04}
+TAG=${1:-r05}
 FUZZ=${2:-240}
 OUT=gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
@@ -47,7 +47,8 @@ python tools/walker_breakdown.py 4096 0 2>/dev/null > $OUT/${TAG}_walker_breakdo
 mkdir -p ab
 SES_OUT=$R/ab/libT.so SES_OBJ=/tmp/objT bash simple-es_amd/csrc/build.sh -DSES_PHASE_TIMERS > /dev/null 2>&1
 for w in walker lander c3; do SES_LIB_PATH=$R/ab/libT.so python tools/walker_phases.py $w 4096 2>/dev/null; done > $OUT/${TAG}_step_phases.txt
-python tools/c3_breakdown.py > $OUT/${TAG}_c3_breakdown.txt 2>&1
+python tools/c3_breakdown.py > $OUT/${TAG}_c3_by_horizon.txt 2>&1
+python tools/time_small_populations.py 2>/dev/null > $OUT/${TAG}_small_populations.txt
 python tools/lander_step_cost.py > $OUT/${TAG}_lander_step_cost.txt 2>&1
 # the multi-rank side (tests excluded: they ran above): exchange latency by kind, a generation of two ranks with and without the
 # fused exchanges, the openai_es tail replicated / in shard form, the 8-rank shapes by kernel
