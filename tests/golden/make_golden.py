@@ -384,8 +384,15 @@ def g9_long():
     theta = np.ascontiguousarray(theta[::stride], dtype=np.float32)
     r, st = returns_of(Cart(init, max_step=500), GymEnvModel(4, 2, True, False), theta, E)
     out["mlp_theta"], out["mlp_returns"], out["mlp_steps"] = theta, r, st
+    # the same policies over a gym-faithful float64 CartPole (gym's statements in double precision, libm sin / cos): how much of
+    # what the fp32 env says about a TRAINED policy survives a change of the physics' precision
+    class Cart64(_EpisodeLog, CartPoleGym64Env):
+        lengths = []
+    r64, _ = returns_of(Cart64(init, max_step=500), GymEnvModel(4, 2, True, False), theta, E)
+    out["mlp_returns_gym64"] = r64
     meta["mlp"] = {"N": int(len(r)), "E": E, "at_cap": int((r == 500).sum()), "ge50_lt500": int(((r >= 50) & (r < 500)).sum()),
-                   "env_steps": int(st.sum())}
+                   "env_steps": int(st.sum()), "same_return_under_gym64": int((r == r64).sum()),
+                   "at_cap_under_both": int(((r == 500) & (r64 == 500)).sum()), "at_cap_under_gym64": int((r64 == 500).sum())}
     print("G9 mlp", meta["mlp"], flush=True)
 
     # (b) POMDP CartPole-v1, GRU (README.md:42): 20 checkpoints of one simple_evolution run + two noise levels
