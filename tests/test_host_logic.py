@@ -76,6 +76,42 @@ def test_fitness_allgather_world_size_8_gloo(tmp_path):
     assert all((tmp_path / f"rank{r}.ok").exists() for r in range(8))
 
 
+AGREE_WORKER = textwrap.dedent("""
+    import sys, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    dist.init_process_group("gloo")
+    from ses.parallel import all_ranks, attach_comm
+    rank = dist.get_rank()
+    dev = torch.device("cpu")
+    # one rank that cannot take the device-side loop (a hook on its loop object, SES_BATCH_GENERATIONS=0 in its environment,
+    # no transport) switches every rank to the per-generation path; everybody able -> everybody takes it
+    assert all_ranks(True, dev) is True
+    assert all_ranks(rank != 1, dev) is False
+    assert all_ranks(False, dev) is False
+    class Handle:                      # attach_comm(create=False) binds to nothing and starts no rendezvous when this process has no owner yet
+        pass
+    h = Handle()
+    if rank == 0:                      # called on ONE rank only: must return at once
+        assert attach_comm(h, create=False) is False and h._comm_owner is None
+    dist.barrier()
+    open(sys.argv[1] + "/agree" + str(rank) + ".ok", "w").write("ok")
+    dist.destroy_process_group()
+""")
+
+
+def test_the_choice_of_the_loop_is_collective_world_size_2_gloo(tmp_path):
+    """ESLoop._generation_batch takes the MIN of the ranks' eligibility over the control plane (ses/parallel.py::all_ranks): the
+    device-side loop and the per-generation path issue different exchanges, so ranks must never decide alone; and a strategy built
+    on a subset of the ranks (attach_comm(create=False)) never starts a rendezvous."""
+    script = tmp_path / "agree.py"
+    script.write_text(AGREE_WORKER % SRC)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script), str(tmp_path)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert (tmp_path / "agree0.ok").exists() and (tmp_path / "agree1.ok").exists()
+
+
 def test_bench_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` without a launcher: the parent starts torch.distributed.run as a child, relays
     rank 0's JSON line and returns the child's exit code (here the ranks only rendezvous: no GPU in this container)."""
