@@ -79,7 +79,10 @@ PARITY_NOTE = ("CartPole (the headline): rollout returns bit-exact vs the C orac
                "(24 openai_es checkpoints, 13 flying all 300 steps in every episode, 2 landing): every episode length equal to the "
                "reference's; returns of episodes that touch the ground differ by 0.44 median / 4.9 max -- the reference's OWN returns "
                "move by 0.55 median / 8.6 max when its parameters are moved one float32 ulp (recorded in the fixture): contact "
-               "dynamics amplify a last-bit action difference, no 1e-4 is attainable there by any implementation.  gym, "
+               "dynamics amplify a last-bit action difference, no 1e-4 is attainable there by any implementation.  G10 (the MLP policies of "
+               "conf/lunarlander.yaml and conf/bipedalwalker.yaml, first-generation and trained): first-generation landers exactly the "
+               "reference's returns and lengths; trained policies inside the reference's own one-ulp envelope (its returns move by up to "
+               "108 / 68 points, 27 % / 15 % of its episode lengths change; ours differ by at most 40 / 38, median 0.05 / 1.25).  gym, "
                "Box2D and pettingzoo are in neither the reference tree nor this image: parity with them is UNPINNED, and "
                "tests/test_optional_gym.py (the float32 lander next to gym's own, needs gym[box2d]) has never run anywhere")
 BOX2D_PARITY = ("device == host build of the same world text, bit for bit (compiler parity); physics: float64 envelope "

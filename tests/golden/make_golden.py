@@ -489,8 +489,91 @@ def g9_long():
         json.dump(meta, f, indent=1)
 
 
+# --------------------------------------------------------------------------- G10 (the Box2D configs' MLP policies)
+def g10_box2d_mlp():
+    """conf/lunarlander.yaml (GymEnvModel(8, 4, discrete_action=False, gru=False), fully observed) and conf/bipedalwalker.yaml
+    (GymEnvModel(24, 4, False, False)): the reference's RolloutWorker + module over the build's env objects, for first-generation
+    policies (sigma 2 around the zero network, what those configs start from) and for elite checkpoints of product runs
+    (tests/golden/g10_seeds.npz, tools/g9_train.py box2d -- input data): landers that land, walkers that walk a little.
+    Forward outputs of the (24, 4) shape teacher-forced on walker observations (G1 has no 24-input case).  As for G9's lander
+    set, the reference's own returns under a one-ulp change of its parameters are recorded beside them."""
+    from oracle.lander_env import LunarLanderEnv
+    from oracle.walker_env import BipedalWalkerEnv
+    seeds = np.load(os.path.join(HERE, "g10_seeds.npz"))
+    out, meta = {}, {}
+    E, K = 3, 3
+    rng = np.random.RandomState(12)
+    init = {"lander": rng.rand(E, 16).astype(np.float32), "walker": rng.rand(E, 4).astype(np.float32)}
+
+    def make_env(tag):
+        class Env(_EpisodeLog, LunarLanderEnv if tag == "lander" else BipedalWalkerEnv):
+            lengths = []
+        return Env(init[tag], max_step=300, pomdp=False) if tag == "lander" else Env(init[tag], max_step=300)
+
+    def returns_of(env, net, theta):
+        rets, steps = [], []
+        env.lengths = []
+        for i in range(theta.shape[0]):
+            load_flat(net, theta[i])
+            env.rewind()
+            env.curr_step = 0
+            rets.append(RolloutWorker((env, {"0": net}, E)))
+            steps.append(env.take_lengths())
+        return np.array(rets, dtype=np.float64), np.array(steps, dtype=np.int32)
+
+    for tag, S in (("lander", 8), ("walker", 24)):
+        net = GymEnvModel(S, 4, False, False)
+        P = flat(net).size
+        first_gen = (rng.standard_normal((12, P)) * 2.0).astype(np.float32)
+        trained = seeds[f"{tag}_mlp"]
+        theta = np.ascontiguousarray(np.concatenate([first_gen, trained]), dtype=np.float32)
+        env = make_env(tag)
+        r, st = returns_of(env, net, theta)
+        ulp_r, ulp_s = [], []
+        urng = np.random.RandomState(13 if tag == "lander" else 14)
+        for k in range(K):
+            up = urng.rand(*theta.shape) < 0.5
+            moved = np.where(up, np.nextafter(theta, np.float32(np.inf)), np.nextafter(theta, np.float32(-np.inf))).astype(np.float32)
+            rk, sk = returns_of(env, net, np.ascontiguousarray(moved))
+            ulp_r.append(rk)
+            ulp_s.append(sk)
+        out[f"{tag}_theta"], out[f"{tag}_init"], out[f"{tag}_returns"], out[f"{tag}_steps"] = theta, init[tag], r, st
+        out[f"{tag}_returns_ulp"], out[f"{tag}_steps_ulp"] = np.stack(ulp_r), np.stack(ulp_s)
+        meta[tag] = {"N": int(len(r)), "first_generation": 12, "trained": int(trained.shape[0]), "E": E, "P": int(P),
+                     "min": float(r.min()), "max": float(r.max()), "episodes_at_300": int((st == 300).sum()),
+                     "env_steps": int(st.sum()), "max_abs_move_of_the_reference_under_one_ulp": float(np.abs(np.stack(ulp_r) - r).max()),
+                     "lengths_equal_under_one_ulp": float(np.mean(np.stack(ulp_s) == st))}
+        print("G10", tag, meta[tag], flush=True)
+
+    # forward of the 24-input shape along one walker episode of a trained policy: observations, pre-activations, actions
+    net = GymEnvModel(24, 4, False, False)
+    vec = seeds["walker_mlp"][-1]
+    load_flat(net, vec)
+    env = BipedalWalkerEnv(init["walker"], max_step=300)
+    states = env.reset()
+    obs, logits, act = [], [], []
+    done = False
+    while not done:
+        o = np.asarray(states["0"]["state"], dtype=np.float32)
+        a = net(o[np.newaxis, ...])
+        with torch.no_grad():
+            x = torch.tanh(net.fc1(torch.from_numpy(o[np.newaxis, ...]).float().unsqueeze(0)))
+            logits.append(net.fc2(x).numpy().reshape(-1))
+        obs.append(o)
+        act.append(np.asarray(a, dtype=np.float32).reshape(-1))
+        states, _, done, _ = env.step({"0": a})
+    out["fwd_walker_theta"], out["fwd_walker_obs"] = vec.astype(np.float32), np.stack(obs)
+    out["fwd_walker_logits"], out["fwd_walker_act"] = np.stack(logits), np.stack(act)
+    meta["fwd_walker_steps"] = len(obs)
+    np.savez_compressed(os.path.join(OUT, "g10_box2d_mlp.npz"), **out)
+    with open(os.path.join(OUT, "g10_box2d_mlp.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g234", "g56", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g234", "g56", "g7", "g8", "g9", "g10"]
+    if "g10" in which:
+        g10_box2d_mlp()
     if "g9" in which:
         g9_long()
     if "g8" in which:

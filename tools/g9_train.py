@@ -13,6 +13,7 @@ These are INPUTS only (where a theta comes from does not matter to the fixture);
 produced by the imported reference in tests/golden/make_golden.py g9.
 
     python tools/g9_train.py gpurun_out/g9_seeds.npz
+    python tools/g9_train.py gpurun_out/g10_seeds.npz box2d      # lander_mlp [k, 420], walker_mlp [k, 932]: fixture G10
 """
 import contextlib
 import glob
@@ -69,6 +70,15 @@ def main():
         out[tag] = np.concatenate([p[0] for p in parts])
         out[tag + "_gen"] = np.concatenate([p[1] for p in parts])
         out[tag + "_best"] = np.concatenate([p[2] for p in parts])
+
+    if len(sys.argv) > 2 and sys.argv[2] == "box2d":
+        # fixture G10: the MLP policies of the reference's two Box2D configs (conf/lunarlander.yaml: 8-32-4, conf/bipedalwalker.yaml:
+        # 24-32-4), elite checkpoints of product runs at the configs' own strategies, larger populations
+        put("lander_mlp", [train("lunarlander.yaml", 240, 10, episodes=3, offspring_num=512)])
+        put("walker_mlp", [train("bipedalwalker.yaml", 160, 8, episodes=3, offspring_num=480)])
+        np.savez_compressed(out_path, **out)
+        print("wrote", out_path, {k: v.shape for k, v in out.items()})
+        return
 
     put("mlp", [train("cartpole.yaml", 60, 3), train("cartpole_openai.yaml", 60, 4, offspring_num=256)])
     put("gru", [train("cartpole_pomdp_gru.yaml", 160, 8)])
