@@ -570,8 +570,43 @@ def g10_box2d_mlp():
         json.dump(meta, f, indent=1)
 
 
+# --------------------------------------------------------------------------- G7t (trained simple_spread teams)
+def g7t_spread_trained():
+    """G7's policies are random; here: elite checkpoints of product runs of conf/simplespread.yaml (2 agents, openai_es) and of the
+    BASELINE shape (3 agents, simple_evolution) -- tests/golden/g7t_seeds.npz, tools/g9_train.py spread, input data -- and seeded
+    perturbations of them, through the reference's RolloutWorker + wrap_agentid over the build's simple_spread env object."""
+    from learning_strategies.evolution.utils import wrap_agentid  # reference
+    from oracle.spread_env import SimpleSpreadF32Env
+    seeds = np.load(os.path.join(HERE, "g7t_seeds.npz"))
+    out, meta = {}, {}
+    E = 5
+    for n_agents in (2, 3):
+        S = 6 * n_agents
+        net = GymEnvModel(S, 5, True, False)
+        rng = np.random.RandomState(200 + n_agents)
+        base = seeds[f"spread{n_agents}"]
+        theta = np.concatenate([base] + [(base + rng.standard_normal(base.shape) * sg).astype(np.float32) for sg in (0.05, 0.3)])
+        theta = np.ascontiguousarray(theta, dtype=np.float32)
+        init = rng.uniform(-1, 1, (E, 4 * n_agents)).astype(np.float32)
+        env = SimpleSpreadF32Env(init, n_agents=n_agents)
+        rets = []
+        for i in range(theta.shape[0]):
+            load_flat(net, theta[i])
+            env.rewind()
+            rets.append(RolloutWorker((env, wrap_agentid(env.get_agent_ids(), net), E)))
+        out[f"n{n_agents}_theta"], out[f"n{n_agents}_init"] = theta, init
+        out[f"n{n_agents}_returns"] = np.array(rets, dtype=np.float64)
+        meta[f"n{n_agents}"] = {"N": int(theta.shape[0]), "E": E, "mean_return": float(np.mean(rets)), "best": float(np.max(rets))}
+        print("G7t spread", n_agents, meta[f"n{n_agents}"], flush=True)
+    np.savez_compressed(os.path.join(OUT, "g7t_spread_trained.npz"), **out)
+    with open(os.path.join(OUT, "g7t_spread_trained.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g234", "g56", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g234", "g56", "g7", "g7t", "g8", "g9", "g10"]
+    if "g7t" in which:
+        g7t_spread_trained()
     if "g10" in which:
         g10_box2d_mlp()
     if "g9" in which:

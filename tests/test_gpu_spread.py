@@ -19,10 +19,11 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+@pytest.mark.parametrize("fixture", ["g7_spread.npz", "g7t_spread_trained.npz"])     # random teams / trained checkpoints + perturbations
 @pytest.mark.parametrize("n_agents", [2, 3])
-def test_spread_rollout_golden_and_oracle(golden_dir, n_agents):
+def test_spread_rollout_golden_and_oracle(golden_dir, n_agents, fixture):
     from ses import HipES
-    g = np.load(os.path.join(golden_dir, "g7_spread.npz"))
+    g = np.load(os.path.join(golden_dir, fixture))
     theta, init = g[f"n{n_agents}_theta"], g[f"n{n_agents}_init"]
     es = HipES("simple_spread", 6 * n_agents, 5, True, False, max_step=25, eval_ep_num=5, n_agents=n_agents)
     fit, ep_ret, _ = es.rollout(dev(theta), dev(init), want_episodes=True)

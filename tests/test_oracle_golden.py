@@ -217,7 +217,7 @@ def test_committed_fixtures_are_what_the_generator_produces(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(here, "golden", "make_golden.py")], capture_output=True, text=True,
                          env={**os.environ, "SES_GOLDEN_OUT": str(tmp_path), "SES_G9_STRIDE": str(stride)}, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
-    inputs = {"g9_seeds.npz", "g10_seeds.npz"}   # parameter vectors harvested from product training runs (tools/g9_train.py): data the generator READS
+    inputs = {"g7t_seeds.npz", "g9_seeds.npz", "g10_seeds.npz"}   # parameter vectors harvested from product training runs (tools/g9_train.py): data the generator READS
     names = sorted(f for f in os.listdir(os.path.join(here, "golden")) if f.endswith((".npz", ".json")) and f not in inputs)
     assert names and sorted(f for f in os.listdir(tmp_path) if f.endswith((".npz", ".json"))) == names
     for f in names:

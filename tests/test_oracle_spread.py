@@ -21,6 +21,19 @@ def test_g7_team_returns_match_reference(golden_dir, n_agents):
     assert (ep < 0).all()                                        # rewards are negative distances / collisions
 
 
+@pytest.mark.parametrize("n_agents", [2, 3])
+def test_g7t_trained_team_returns_match_reference(golden_dir, n_agents):
+    """G7's teams are random; G7t: 20 elite checkpoints of product runs (conf/simplespread.yaml and the three-agent BASELINE shape)
+    and 40 seeded perturbations of them per shape, returns from the reference's RolloutWorker + wrap_agentid: 120 / 120 within
+    1e-4 (observed 3.8e-6: no argmax of 5 actions flipped in 37 500 agent-steps)."""
+    g = np.load(os.path.join(golden_dir, "g7t_spread_trained.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g7t_spread_trained.json")))[f"n{n_agents}"]
+    theta, init = g[f"n{n_agents}_theta"], g[f"n{n_agents}_init"]
+    assert theta.shape == (meta["N"], co.param_count(6 * n_agents, 5, False)) and meta["N"] >= 60
+    fit, _ = co.rollout_spread(theta, init, meta["E"], n_agents)
+    assert np.abs(fit.astype(np.float64) - g[f"n{n_agents}_returns"]).max() <= 1e-4
+
+
 def test_env_protocol_and_observation_layout():
     init = np.array([[0.5, -0.25, -0.5, 0.75, 0.1, 0.2, -0.3, -0.4]], np.float32)   # 2 agents, 2 landmarks
     env = SimpleSpreadF32Env(init, n_agents=2)

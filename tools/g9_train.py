@@ -40,6 +40,10 @@ def train(cfg_name, gens, period, episodes=5, **override):
     cfg = yaml.load(open(os.path.join(ROOT, "simple-es_amd", "conf", cfg_name)), Loader=yaml.FullLoader)
     for k, v in override.items():
         cfg["strategy"][k] = v
+    if globals().get("_ENV3"):                       # simple_spread with three agents: 18 observations
+        cfg["env"]["n_agents"] = 3
+        cfg["network"]["num_state"] = 18
+        cfg["strategy"].pop("learning_rate", None)
     cfg["strategy"].setdefault("seed", 0)
     cfg["env"].setdefault("seed", 0)
     os.chdir(tempfile.mkdtemp())
@@ -71,6 +75,17 @@ def main():
         out[tag + "_gen"] = np.concatenate([p[1] for p in parts])
         out[tag + "_best"] = np.concatenate([p[2] for p in parts])
 
+    if len(sys.argv) > 2 and sys.argv[2] == "spread":
+        # trained simple_spread teams for G7's extension: conf/simplespread.yaml (2 agents, openai_es) and the BASELINE shape
+        # (3 agents, simple_evolution)
+        put("spread2", [train("simplespread.yaml", 300, 15, episodes=5, offspring_num=512)])
+        cfg3 = {"name": "simple_evolution", "init_sigma": 1.0, "sigma_decay": 0.999, "elite_num": 16, "offspring_num": 512}
+        global _ENV3
+        _ENV3 = True
+        put("spread3", [train("simplespread.yaml", 300, 15, episodes=5, **cfg3)])
+        np.savez_compressed(out_path, **out)
+        print("wrote", out_path, {k: v.shape for k, v in out.items()})
+        return
     if len(sys.argv) > 2 and sys.argv[2] == "box2d":
         # fixture G10: the MLP policies of the reference's two Box2D configs (conf/lunarlander.yaml: 8-32-4, conf/bipedalwalker.yaml:
         # 24-32-4), elite checkpoints of product runs at the configs' own strategies, larger populations
