@@ -67,7 +67,8 @@ PARITY_NOTE = ("CartPole (the headline): rollout returns bit-exact vs the C orac
                "float64 CartPole: all 186 G9 policies at the cap are at the cap there too (same return for 267 of the 315; env.physics: "
                "float64 for 306), and the same return for 95 % of "
                "the G5 policies (99.2 % with env.physics: float64) -- gym itself is not pinned by the reference.  "
-               "simple_spread: bit-exact vs an independently written C oracle, within 1e-4 of the reference RolloutWorker (G7).  "
+               "simple_spread: bit-exact vs an independently written C oracle, within 1e-4 of the reference RolloutWorker for 96 random teams (G7) "
+               "and 120 trained ones (G7t), 2 and 3 agents: 216 / 216.  "
                "LunarLander / BipedalWalker: 'bit-exact vs the oracle' there means the DEVICE build equals the HOST build of one "
                "source text (the Box2D-style world): it pins the compiler, not the physics.  The physics is held to envelopes "
                "around independently written float64 integrations -- lander yes (oracle/lander64.c: flights within 1.5e-3 of "
