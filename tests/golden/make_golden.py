@@ -603,8 +603,66 @@ def g7t_spread_trained():
         json.dump(meta, f, indent=1)
 
 
+# --------------------------------------------------------------------------- G6es (the reference's ESLoop with openai_es, end to end)
+def g6es_openai_loop():
+    """conf/lunarlander_openai.yaml's shape at a smaller population: the reference's ESLoop.run() with openai_es (GRU policy,
+    POMDP LunarLanderContinuous-v2 over the build's env object, process_num = 1) for four generations -- population matrices, returns,
+    parent, Adam moments and sigma per generation, captured by wrapping evaluate.  Float rewards: no ties, so the rank shaping does
+    not depend on numpy's tie order (CartPole's returns tie massively)."""
+    from oracle.lander_env import LunarLanderEnv
+    out, meta = {}, {}
+    E, gens, offs = 3, 4, 16
+    init = np.random.RandomState(21).rand(E, 16).astype(np.float32)
+    out["init"] = init
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    try:
+        set_seed(5)
+        env = LunarLanderEnv(init, max_step=300, pomdp=True)
+        net = GymEnvModel(8, 4, False, True)
+        strat = openai_es(1.0, 0.999, 0.087, offs)     # (sigma 1, not the config's 0.168: near-zero policies never fire an engine and
+        loop = ESLoop({}, strat, env, net, gens, 1, E, False, 10 ** 9)       #  fall identically -- exact ties in every generation)
+        trace = {"rewards": [], "theta": [], "best": [], "sigma": [], "mu": [], "m": [], "v": []}
+        orig_eval, orig_init = strat.evaluate, strat.init_offspring
+
+        def init_wrapped(network, agent_ids):
+            pop = orig_init(network, agent_ids)
+            trace["theta"].append(pop_matrix(pop))
+            return pop
+
+        def eval_wrapped(rewards):
+            trace["rewards"].append(np.array(rewards, dtype=np.float64))
+            pop, best, sigma = orig_eval(rewards)
+            trace["theta"].append(pop_matrix(pop))
+            trace["best"].append(float(best))
+            trace["sigma"].append(float(sigma))
+            trace["mu"].append(flat(strat.mu_model))
+            trace["m"].append(np.concatenate([x.reshape(-1) for x in strat.optimizer.m]).astype(np.float32))
+            trace["v"].append(np.concatenate([x.reshape(-1) for x in strat.optimizer.v]).astype(np.float32))
+            return pop, best, sigma
+
+        strat.init_offspring, strat.evaluate = init_wrapped, eval_wrapped
+        loop.run()
+    finally:
+        os.chdir(cwd)
+    for g in range(gens):
+        out[f"theta{g}"], out[f"returns{g}"] = trace["theta"][g], trace["rewards"][g]
+        out[f"mu{g + 1}"], out[f"m{g + 1}"], out[f"v{g + 1}"] = trace["mu"][g], trace["m"][g], trace["v"][g]
+    out[f"theta{gens}"] = trace["theta"][gens]
+    gaps = [float(np.diff(np.sort(r)).min()) for r in trace["rewards"]]
+    meta = {"gens": gens, "offspring_num": offs, "E": E, "seed": 5, "init_sigma": 1.0, "sigma_decay": 0.999, "learning_rate": 0.087,
+            "best": trace["best"], "sigma": trace["sigma"], "smallest_gap_between_two_returns": gaps}
+    np.savez_compressed(os.path.join(OUT, "g6es_openai_loop.npz"), **out)
+    with open(os.path.join(OUT, "g6es_openai_loop.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("G6es", {k: meta[k] for k in ("best", "sigma", "smallest_gap_between_two_returns")}, flush=True)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g234", "g56", "g7", "g7t", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g234", "g56", "g6es", "g7", "g7t", "g8", "g9", "g10"]
+    if "g6es" in which:
+        g6es_openai_loop()
     if "g7t" in which:
         g7t_spread_trained()
     if "g10" in which:

@@ -194,6 +194,34 @@ def test_g6_esloop_trace(g56, tag):
         assert best == m["best"][g] and sigma == m["sigma"][g]
 
 
+def test_g6es_openai_es_loop_end_to_end(golden_dir):
+    """The reference's ESLoop.run() with openai_es -- the headline strategy -- end to end (GRU policy on the POMDP lander, float
+    returns: tie-free, smallest gap between two returns 6.4): population by strategies_np from the reference's noise stream (bit for
+    bit), rollout by the C oracle, and the OWN returns fed back -- NOT the reference's: they differ in the third to fifth digit,
+    the ranks are the same, so parent, Adam moments and the next population stay the reference's bit for bit through all
+    four generations."""
+    data = np.load(os.path.join(golden_dir, "g6es_openai_loop.npz"))
+    m = json.load(open(os.path.join(golden_dir, "g6es_openai_loop.json")))
+    assert min(m["smallest_gap_between_two_returns"]) > 1.0
+    P = co.param_count(8, 4, True)
+    np.random.seed(m["seed"])
+    strat = snp.OpenAIESNP(P, m["init_sigma"], m["sigma_decay"], m["learning_rate"], m["offspring_num"])
+    for g in range(m["gens"]):
+        theta = strat.theta()
+        assert np.array_equal(theta, data[f"theta{g}"]), f"population differs at generation {g}"
+        fit, _, _ = co.rollout_lander(theta, data["init"], m["E"], 300)
+        ref = data[f"returns{g}"]
+        # sigma-1 policies fly, some for all 300 steps and through leg contacts: the returns differ by up to 1.15 (1.8e-3 relative;
+        # 3e-5 where the flight ends in a crash) -- far inside the gaps between them, which is all the rank shaping sees
+        np.testing.assert_allclose(fit.astype(np.float64), ref, rtol=5e-3, atol=1e-3)
+        assert np.array_equal(np.argsort(fit), np.argsort(ref))
+        best, sigma = strat.evaluate([float(x) for x in fit])
+        assert abs(best - m["best"][g]) <= 5e-3 * abs(m["best"][g]) and sigma == m["sigma"][g]
+        assert np.array_equal(strat.mu, data[f"mu{g + 1}"])
+        assert np.array_equal(strat.optimizer.m, data[f"m{g + 1}"]) and np.array_equal(strat.optimizer.v, data[f"v{g + 1}"])
+    assert np.array_equal(strat.theta(), data[f"theta{m['gens']}"])
+
+
 def test_physics64_closes_most_of_the_gap_to_gym_float64(g56):
     """Gym-order float64 CartPole (physics64): per-offspring returns agree with the reference RolloutWorker over
     a gym-faithful float64 env (math.sin/cos, ** 2) for >= 99 % of the fixture, vs ~95 % for the fp32 dynamics.
