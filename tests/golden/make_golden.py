@@ -659,10 +659,71 @@ def g6es_openai_loop():
     print("G6es", {k: meta[k] for k in ("best", "sigma", "smallest_gap_between_two_returns")}, flush=True)
 
 
+# --------------------------------------------------------------------------- G6gen (the reference's ESLoop with simple_genetic, end to end)
+def g6gen_genetic_loop():
+    """The reference's ESLoop.run() with simple_genetic (the strategy of conf/bipedalwalker.yaml) end to end over the build's CartPole
+    (MLP policy, 6 elites x 4 = 24 members, five episodes, six generations): population matrices and returns per generation, captured
+    like G6.  CartPole because its returns are reproduced exactly (G5 / G9) and a population learns within generations; its returns
+    tie (multiples of 1 / E), and numpy's unstable argsort orders ties by version, so per generation the fixture records whether the
+    elite cut-off is tie-free -- where it is, the next population must come out bit for bit (as in G6)."""
+    out = {}
+    E, gens, k, offs = 5, 6, 6, 24
+    init = np.random.RandomState(0).uniform(-0.05, 0.05, (E, 4)).astype(np.float32)
+    out["init_states"] = init
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    try:
+        set_seed(3)
+        env = CartPoleF32Env(init, max_step=500)
+        net = GymEnvModel(4, 2, True, False)
+        strat = simple_genetic(2.0, 0.999, k, offs)
+        loop = ESLoop({}, strat, env, net, gens, 1, E, False, 10 ** 9)
+        trace = {"rewards": [], "theta": [], "best": [], "sigma": []}
+        orig_eval, orig_init = strat.evaluate, strat.init_offspring
+
+        def init_wrapped(network, agent_ids):
+            pop = orig_init(network, agent_ids)
+            trace["theta"].append(pop_matrix(pop))
+            return pop
+
+        def eval_wrapped(rewards):
+            trace["rewards"].append(np.array(rewards, dtype=np.float64))
+            pop, best, sigma = orig_eval(rewards)
+            trace["theta"].append(pop_matrix(pop))
+            trace["best"].append(float(best))
+            trace["sigma"].append(float(sigma))
+            return pop, best, sigma
+
+        strat.init_offspring, strat.evaluate = init_wrapped, eval_wrapped
+        loop.run()
+    finally:
+        os.chdir(cwd)
+    tie_free = []
+    for g in range(gens):
+        out[f"theta{g}"], out[f"returns{g}"] = trace["theta"][g], trace["rewards"][g]
+        r, th = trace["rewards"][g], trace["theta"][g]
+        order = np.argsort(-r, kind="stable")
+        # the cut-off is tie-free when no row outside the top k has the k-th return and rows tied INSIDE the top k are ... still a
+        # matter of order (the elites are laid out in rank order): tie-free means all of the top k + 1 returns are distinct
+        top = r[order[: k + 1]]
+        tie_free.append(bool(len(np.unique(top)) == len(top)))
+    out[f"theta{gens}"] = trace["theta"][gens]
+    meta = {"gens": gens, "offspring_num": offs, "elite_num": k, "E": E, "seed": 3, "init_sigma": 2.0, "sigma_decay": 0.999,
+            "best": trace["best"], "sigma": trace["sigma"], "pop": [int(t.shape[0]) for t in trace["theta"]],
+            "tie_free_cutoff": tie_free}
+    np.savez_compressed(os.path.join(OUT, "g6gen_genetic_loop.npz"), **out)
+    with open(os.path.join(OUT, "g6gen_genetic_loop.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("G6gen", {k_: meta[k_] for k_ in ("best", "sigma", "pop", "tie_free_cutoff")}, flush=True)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g234", "g56", "g6es", "g7", "g7t", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g234", "g56", "g6es", "g6gen", "g7", "g7t", "g8", "g9", "g10"]
     if "g6es" in which:
         g6es_openai_loop()
+    if "g6gen" in which:
+        g6gen_genetic_loop()
     if "g7t" in which:
         g7t_spread_trained()
     if "g10" in which:

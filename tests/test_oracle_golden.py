@@ -222,6 +222,26 @@ def test_g6es_openai_es_loop_end_to_end(golden_dir):
     assert np.array_equal(strat.theta(), data[f"theta{m['gens']}"])
 
 
+def test_g6gen_simple_genetic_loop_end_to_end(golden_dir):
+    """The reference's ESLoop.run() with simple_genetic (conf/bipedalwalker.yaml's strategy) end to end over the build's CartPole:
+    population by strategies_np from the reference's noise stream, rollout by the C oracle, its OWN returns fed back; every
+    generation's elite cut-off is tie-free in this trace, so all seven populations are the reference's bit for bit."""
+    data = np.load(os.path.join(golden_dir, "g6gen_genetic_loop.npz"))
+    m = json.load(open(os.path.join(golden_dir, "g6gen_genetic_loop.json")))
+    assert all(m["tie_free_cutoff"]) and m["best"][-1] > m["best"][0]           # and the elites change along the way
+    P = co.param_count(4, 2, False)
+    np.random.seed(m["seed"])
+    strat = snp.SimpleGeneticNP(P, m["init_sigma"], m["sigma_decay"], m["elite_num"], m["offspring_num"])
+    for g in range(m["gens"]):
+        theta = strat.theta()
+        assert np.array_equal(theta, data[f"theta{g}"]), f"population differs at generation {g}"
+        fit, _, _ = co.rollout_cartpole(theta, data["init_states"], m["E"], 500)
+        assert np.abs(fit.astype(np.float64) - data[f"returns{g}"]).max() <= RETURN_TOL
+        best, sigma = strat.evaluate([float(x) for x in fit])
+        assert abs(best - m["best"][g]) <= RETURN_TOL and sigma == m["sigma"][g]
+    assert np.array_equal(strat.theta(), data[f"theta{m['gens']}"])
+
+
 def test_physics64_closes_most_of_the_gap_to_gym_float64(g56):
     """Gym-order float64 CartPole (physics64): per-offspring returns agree with the reference RolloutWorker over
     a gym-faithful float64 env (math.sin/cos, ** 2) for >= 99 % of the fixture, vs ~95 % for the fp32 dynamics.
