@@ -58,7 +58,10 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured achievable
 BYTES_PER_ENV_STEP = 52        # 7 dword loads + 6 dword stores
 METRIC = "env-steps/sec (whole node), CartPole openai_es pop=4096 at 1/2/4/8 GPUs"
-PARITY_NOTE = ("CartPole (the headline): rollout returns bit-exact vs the C oracle; within 1e-4 of the reference RolloutWorker driven "
+PARITY_NOTE = ("Strategies: the reference's own ESLoop.run() reproduced end to end for all three (fixtures G6 simple_evolution, G6gen "
+               "simple_genetic, G6es openai_es with real rollouts: populations, parent and Adam moments bit for bit on the device's own "
+               "returns wherever the trace is tie-free), and the product's ESLoop.run() against it from a config dict.  "
+               "CartPole (the headline): rollout returns bit-exact vs the C oracle; within 1e-4 of the reference RolloutWorker driven "
                "over the build's own fp32 CartPole (fixture G5: random / barely trained policies, median episode 12 steps) AND on "
                "long-lived ones (fixture G9, trained checkpoints + perturbations: 315 MLP policies, 186 at the 500 cap, 75 between "
                "50 and 500; 48 POMDP GRU policies, 19 at the cap): measured exact-match rate 363 / 363 = 100 %, every one of the "
