@@ -718,12 +718,77 @@ def g6gen_genetic_loop():
     print("G6gen", {k_: meta[k_] for k_ in ("best", "sigma", "pop", "tie_free_cutoff")}, flush=True)
 
 
+# --------------------------------------------------------------------------- G6evo (simple_evolution, a tie-free trace)
+def g6evo_evolution_loop():
+    """G6's simple_evolution traces contain generations whose elite cut-off ties (CartPole returns are multiples of 1 / E), where the
+    next population depends on numpy's tie order.  This one is searched for: the first seed from 0 whose six generations all have
+    k + 1 distinct top returns (conf/cartpole.yaml's strategy at 24 offspring, 6 elites) -- so that the PRODUCT's ESLoop.run() can be
+    held to the reference's, bit for bit, without teacher forcing."""
+    E, gens, k, offs = 5, 6, 6, 24
+    init = np.random.RandomState(0).uniform(-0.05, 0.05, (E, 4)).astype(np.float32)
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    os.chdir(tmp)
+    try:
+        for seed in range(64):
+            set_seed(seed)
+            env = CartPoleF32Env(init, max_step=500)
+            net = GymEnvModel(4, 2, True, False)
+            strat = simple_evolution(2.0, 0.9999, k, offs)
+            loop = ESLoop({}, strat, env, net, gens, 1, E, False, 10 ** 9)
+            trace = {"rewards": [], "theta": [], "best": [], "sigma": []}
+            orig_eval, orig_init = strat.evaluate, strat.init_offspring
+
+            def init_wrapped(network, agent_ids, _o=orig_init, _t=trace):
+                pop = _o(network, agent_ids)
+                _t["theta"].append(pop_matrix(pop))
+                return pop
+
+            def eval_wrapped(rewards, _o=orig_eval, _t=trace):
+                _t["rewards"].append(np.array(rewards, dtype=np.float64))
+                pop, best, sigma = _o(rewards)
+                _t["theta"].append(pop_matrix(pop))
+                _t["best"].append(float(best))
+                _t["sigma"].append(float(sigma))
+                return pop, best, sigma
+
+            strat.init_offspring, strat.evaluate = init_wrapped, eval_wrapped
+            with open(os.devnull, "w") as sink:
+                import contextlib
+                with contextlib.redirect_stdout(sink):
+                    loop.run()
+            # slots 0 and 1 of a simple_evolution population are the same vector (SURVEY 3.4-6): their returns tie by construction
+            # and their order does not change a value; every OTHER return among the top k + 2 must be distinct
+            ok = True
+            for r in trace["rewards"]:
+                top = np.sort(np.delete(r, 1))[::-1][: k + 1]
+                ok = ok and len(np.unique(top)) == len(top)
+            if ok:
+                break
+        else:
+            raise RuntimeError("no tie-free seed below 64")
+    finally:
+        os.chdir(cwd)
+    out = {"init_states": init}
+    for g in range(gens):
+        out[f"theta{g}"], out[f"returns{g}"] = trace["theta"][g], trace["rewards"][g]
+    out[f"theta{gens}"] = trace["theta"][gens]
+    meta = {"gens": gens, "offspring_num": offs, "elite_num": k, "E": E, "seed": seed, "init_sigma": 2.0, "sigma_decay": 0.9999,
+            "best": trace["best"], "sigma": trace["sigma"], "pop": [int(t.shape[0]) for t in trace["theta"]]}
+    np.savez_compressed(os.path.join(OUT, "g6evo_evolution_loop.npz"), **out)
+    with open(os.path.join(OUT, "g6evo_evolution_loop.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("G6evo", {k_: meta[k_] for k_ in ("seed", "best", "pop")}, flush=True)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g234", "g56", "g6es", "g6gen", "g7", "g7t", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g234", "g56", "g6es", "g6gen", "g6evo", "g7", "g7t", "g8", "g9", "g10"]
     if "g6es" in which:
         g6es_openai_loop()
     if "g6gen" in which:
         g6gen_genetic_loop()
+    if "g6evo" in which:
+        g6evo_evolution_loop()
     if "g7t" in which:
         g7t_spread_trained()
     if "g10" in which:

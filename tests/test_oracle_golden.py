@@ -242,6 +242,23 @@ def test_g6gen_simple_genetic_loop_end_to_end(golden_dir):
     assert np.array_equal(strat.theta(), data[f"theta{m['gens']}"])
 
 
+def test_g6evo_simple_evolution_tie_free_loop(golden_dir):
+    """A simple_evolution trace of the reference's ESLoop.run() whose elite cut-offs are all tie-free (searched for by the generator):
+    strategies_np + the C oracle on its own returns reproduce all seven populations bit for bit."""
+    data = np.load(os.path.join(golden_dir, "g6evo_evolution_loop.npz"))
+    m = json.load(open(os.path.join(golden_dir, "g6evo_evolution_loop.json")))
+    np.random.seed(m["seed"])
+    strat = snp.SimpleEvolutionNP(co.param_count(4, 2, False), m["init_sigma"], m["sigma_decay"], m["elite_num"], m["offspring_num"])
+    for g in range(m["gens"]):
+        theta = strat.theta()
+        assert theta.shape[0] == m["pop"][g] and np.array_equal(theta, data[f"theta{g}"]), f"population differs at generation {g}"
+        fit, _, _ = co.rollout_cartpole(theta, data["init_states"], m["E"], 500)
+        assert np.abs(fit.astype(np.float64) - data[f"returns{g}"]).max() <= RETURN_TOL
+        best, sigma = strat.evaluate([float(x) for x in fit])
+        assert abs(best - m["best"][g]) <= RETURN_TOL and sigma == m["sigma"][g]
+    assert np.array_equal(strat.theta(), data[f"theta{m['gens']}"])
+
+
 def test_physics64_closes_most_of_the_gap_to_gym_float64(g56):
     """Gym-order float64 CartPole (physics64): per-offspring returns agree with the reference RolloutWorker over
     a gym-faithful float64 env (math.sin/cos, ** 2) for >= 99 % of the fixture, vs ~95 % for the fp32 dynamics.
