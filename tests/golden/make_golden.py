@@ -731,6 +731,7 @@ def g6evo_evolution_loop():
     os.chdir(tmp)
     try:
         for seed in range(64):
+            os.chdir(tempfile.mkdtemp())          # (the reference's log directory is named by the second: loop.py:40-47)
             set_seed(seed)
             env = CartPoleF32Env(init, max_step=500)
             net = GymEnvModel(4, 2, True, False)
