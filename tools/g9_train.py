@@ -14,6 +14,7 @@ produced by the imported reference in tests/golden/make_golden.py g9.
 
     python tools/g9_train.py gpurun_out/g9_seeds.npz
     python tools/g9_train.py gpurun_out/g10_seeds.npz box2d      # lander_mlp [k, 420], walker_mlp [k, 932]: fixture G10
+    python tools/g9_train.py gpurun_out/g7t_seeds.npz spread     # spread2 [k, 581], spread3 [k, 773]: fixture G7t
 """
 import contextlib
 import glob
@@ -36,11 +37,11 @@ KEYS_GRU = ["fc1.weight", "fc1.bias", "gru.weight_ih_l0", "gru.weight_hh_l0", "g
             "fc2.weight", "fc2.bias"]
 
 
-def train(cfg_name, gens, period, episodes=5, **override):
+def train(cfg_name, gens, period, episodes=5, three_agents=False, **override):
     cfg = yaml.load(open(os.path.join(ROOT, "simple-es_amd", "conf", cfg_name)), Loader=yaml.FullLoader)
     for k, v in override.items():
         cfg["strategy"][k] = v
-    if globals().get("_ENV3"):                       # simple_spread with three agents: 18 observations
+    if three_agents:                                 # simple_spread with three agents: 18 observations (BASELINE configs[4])
         cfg["env"]["n_agents"] = 3
         cfg["network"]["num_state"] = 18
         cfg["strategy"].pop("learning_rate", None)
@@ -80,9 +81,7 @@ def main():
         # (3 agents, simple_evolution)
         put("spread2", [train("simplespread.yaml", 300, 15, episodes=5, offspring_num=512)])
         cfg3 = {"name": "simple_evolution", "init_sigma": 1.0, "sigma_decay": 0.999, "elite_num": 16, "offspring_num": 512}
-        global _ENV3
-        _ENV3 = True
-        put("spread3", [train("simplespread.yaml", 300, 15, episodes=5, **cfg3)])
+        put("spread3", [train("simplespread.yaml", 300, 15, episodes=5, three_agents=True, **cfg3)])
         np.savez_compressed(out_path, **out)
         print("wrote", out_path, {k: v.shape for k, v in out.items()})
         return
