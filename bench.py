@@ -25,11 +25,17 @@ each with the transport of the all-gather, its time and the per-rank fitness-loo
 the same generations with both exchanges forced onto ncclAllGather ("absent" where no RCCL communicator spans the ranks);
 at N > 1 also `allgather_microbench` (the exchange alone over each transport).  `e1`: the headline job with --eval-ep-num 1.
 
-Extra legs (rank 0): `roofline` -- the standalone SoA env-step kernel at 2^24 envs against the HBM roof
-(SURVEY 8d: 52 algorithmic bytes per env-step), timed with HIP events on the launch stream;
-`loop_ms_per_generation` -- ESLoop.run() itself, prints and metrics included;
-`c3_lunarlander_pomdp_gru_4096` / `box2d_mlp_4096` -- one rollout of BASELINE configs[2] and of the Box2D MLP configs (N = 1);
-`cpu_baseline` -- the reference-structured Python multiprocessing port on the host cores (N = 1 only).
+Extra legs (rank 0): `cpu_baseline` -- the reference-structured Python multiprocessing port on the host cores (N = 1 only; it
+runs FIRST, before this process has touched the GPU, so that whoever samples the GPU's activity from outside finds the GPU legs
+in one piece afterwards); `roofline` -- the standalone SoA env-step kernel at 2^24 envs against the HBM roof (52
+algorithmic bytes per env-step), timed with HIP events on the launch stream; `loop_ms_per_generation` -- ESLoop.run() itself,
+prints and metrics included; `c3_lunarlander_pomdp_gru_4096` / `box2d_mlp_4096` -- one rollout of BASELINE configs[2] and of the
+Box2D MLP configs (N = 1); `small_shards` -- the rollout at the per-GPU populations of the strong line with `strong_expected`.
+
+At N > 1 every job carries a `shard_check` (the run certifies itself on the box it is timed on): one generation's all-gathered
+fitness vector against rank 0's OWN rollout of the whole population, and the parent / Adam moments after a few generations of the
+timed path against rank 0's own single-rank replay from the same snapshot -- `bit_equal` must be true on every rank; each `*_rccl`
+twin asserts that its communicator spans all N ranks.  `legs_wall_s` / `legs_gpu_event_s` say where the run's time went.
 """
 import os
 
@@ -60,7 +66,15 @@ BYTES_PER_ENV_STEP = 52        # 7 dword loads + 6 dword stores
 METRIC = "env-steps/sec (whole node), CartPole openai_es pop=4096 at 1/2/4/8 GPUs"
 PARITY_NOTE = ("Strategies: the reference's own ESLoop.run() reproduced end to end for all three (fixtures G6 simple_evolution, G6gen "
                "simple_genetic, G6es openai_es with real rollouts: populations, parent and Adam moments bit for bit on the device's own "
-               "returns wherever the trace is tie-free), and the product's ESLoop.run() against it from a config dict.  "
+               "returns wherever the trace is tie-free; what is NOT bitwise there: the lander returns of G6es, asserted within rtol "
+               "5e-3 of the reference's with identical ranking, and its per-generation best within 5e-3 relative / 1.0 absolute), and "
+               "the product's ESLoop.run() against it from a config dict.  "
+               "Ties (fixture G4t, CartPole-shaped returns with 30-90 % of the population at the 500 cap): the reference ranks "
+               "with numpy's UNSTABLE argsort, the build with a defined order (return, then index, descending); against the "
+               "order the reference's own evaluate() used on numpy 2.2.6 / AVX-512 the stable rule picks 87 % of the same elite "
+               "individuals (min 80 %; every elite's RETURN is the same: all are tied at the cap) and gives 37 % of the "
+               "openai_es offspring the same shaped weight (the weight of every tie class as a whole is equal; update direction "
+               "cosine 0.66-0.95): among equals both choices are arbitrary.  "
                "CartPole (the headline): rollout returns bit-exact vs the C oracle; within 1e-4 of the reference RolloutWorker driven "
                "over the build's own fp32 CartPole (fixture G5: random / barely trained policies, median episode 12 steps) AND on "
                "long-lived ones (fixture G9, trained checkpoints + perturbations: 315 MLP policies, 186 at the 500 cap, 75 between "
@@ -84,8 +98,8 @@ PARITY_NOTE = ("Strategies: the reference's own ESLoop.run() reproduced end to e
                "reference's; returns of episodes that touch the ground differ by 0.44 median / 4.9 max -- the reference's OWN returns "
                "move by 0.55 median / 8.6 max when its parameters are moved one float32 ulp (recorded in the fixture): contact "
                "dynamics amplify a last-bit action difference, no 1e-4 is attainable there by any implementation.  G10 (the MLP policies of "
-               "conf/lunarlander.yaml and conf/bipedalwalker.yaml, first-generation and trained): first-generation landers exactly the "
-               "reference's returns and lengths; trained policies inside the reference's own one-ulp envelope (its returns move by up to "
+               "conf/lunarlander.yaml and conf/bipedalwalker.yaml, first-generation and trained): first-generation landers every episode "
+               "length equal to the reference's, returns within rtol 1e-5 + atol 1e-3 of them; trained policies inside the reference's own one-ulp envelope (its returns move by up to "
                "108 / 68 points, 27 % / 15 % of its episode lengths change; ours differ by at most 40 / 38, median 0.05 / 1.25).  gym, "
                "Box2D and pettingzoo are in neither the reference tree nor this image: parity with them is UNPINNED, and "
                "tests/test_optional_gym.py (the float32 lander next to gym's own, needs gym[box2d]) has never run anywhere")
@@ -103,7 +117,14 @@ def parse():
     ap.add_argument("--preroll", type=int, default=-1,
                     help="untimed generations run before the warm-up so that the clocks have ramped whatever --warmup "
                          "is (default: enough to make preroll + warmup = 300, about 75 ms); reported in config")
-    ap.add_argument("--offspring-per-gpu", type=int, default=4096)
+    ap.add_argument("--offspring-total", type=int, default=4096,
+                    help="population of the headline job IN TOTAL, sharded over the GPUs (BASELINE's metric: pop=4096)")
+    ap.add_argument("--offspring-per-gpu", type=int, default=4096,
+                    help="population PER GPU of the weak leg (weak_4096_per_gpu) and of e1; until round 5 this flag also set the "
+                         "headline's total")
+    ap.add_argument("--min-timed-seconds", type=float, default=6.0,
+                    help="the headline's --steps block is repeated until the timed blocks cover at least this long "
+                         "(never fewer than --blocks): a 0.1 s measurement is invisible to a utilisation sampler")
     ap.add_argument("--eval-ep-num", type=int, default=5)
     ap.add_argument("--max-step", type=int, default=500)
     ap.add_argument("--roofline-envs", type=int, default=1 << 24)
@@ -272,10 +293,10 @@ def attach_traffic(roofline, n_env):
 class Job:
     """One population size driven through the product loop (builder.build_loop -> ESLoop + openai_es)."""
 
-    def __init__(self, args, n_global, world):
+    def __init__(self, args, n_global, world, E=None):
         import builder
         self.n_global, self.world = n_global, world
-        self.E, self.T = args.eval_ep_num, args.max_step
+        self.E, self.T = (args.eval_ep_num if E is None else E), args.max_step
         cfg = {"env": {"name": "CartPole-v1", "max_step": self.T, "pomdp": bool(args.gru), "seed": 0,
                        "shared_init": True, "fixed_length": True},
                "network": {"name": "gym_model", "num_state": 4, "num_action": 2, "discrete_action": True,
@@ -331,10 +352,11 @@ def exchange_counts(job):
     return owner.comm_p2p_counts() if owner is not None and owner.comm_route()[0] else None
 
 
-def timed_blocks(job, steps, blocks, barrier, dist, world):
-    """`blocks` times: EXACTLY `steps` generations between barrier + synchronize on both sides, MAX over ranks."""
+def timed_blocks(job, steps, blocks, barrier, dist, world, min_seconds=0.0, max_blocks=4000):
+    """`blocks` times (more, until they cover `min_seconds`): EXACTLY `steps` generations between barrier + synchronize on
+    both sides, MAX over ranks.  Every rank sees the same MAX, so every rank stops after the same block."""
     out = []
-    for _ in range(blocks):
+    while len(out) < blocks or (sum(out) < min_seconds and len(out) < max_blocks):
         barrier()
         t0 = time.perf_counter()
         job.generations(steps)
@@ -353,7 +375,363 @@ def summarise(job, steps, times):
     med = statistics.median(per)
     return {"offspring_total": job.n_global, "offspring_per_gpu": -(-job.n_global // job.world),
             "value": job.steps_per_generation() / med, "unit": "env-steps/s", "ms_per_step": med * 1e3,
-            "ms_per_step_min": per[0] * 1e3, "ms_per_step_max": per[-1] * 1e3, "blocks": len(per), "steps": steps}
+            "ms_per_step_min": per[0] * 1e3, "ms_per_step_max": per[-1] * 1e3, "blocks": len(per), "steps": steps,
+            "timed_seconds": sum(times)}
+
+
+class Legs:
+    """Where the run's time went: wall seconds per leg (this rank) and, for the legs that enqueue GPU work, the span between a
+    HIP event recorded on the launch stream when the leg starts and one when it ends."""
+
+    def __init__(self):
+        self.wall, self.gpu, self._open = {}, {}, None
+
+    def begin(self, name, gpu=True):
+        self._open = self.leg(name, gpu)
+        self._open.__enter__()
+
+    def end(self):
+        if self._open is not None:
+            self._open.__exit__(None, None, None)
+            self._open = None
+
+    @contextlib.contextmanager
+    def leg(self, name, gpu=True):
+        t0 = time.perf_counter()
+        ev = None
+        if gpu:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        try:
+            yield
+        finally:
+            if ev is not None:
+                ev[1].record()
+                ev[1].synchronize()
+                self.gpu[name] = self.gpu.get(name, 0.0) + ev[0].elapsed_time(ev[1]) * 1e-3
+            self.wall[name] = self.wall.get(name, 0.0) + time.perf_counter() - t0
+
+
+def _bcast_from_rank0(t, dist, backend):
+    """Rank 0's tensor on every rank (gloo rigs: staged through the host)."""
+    if backend == "nccl":
+        dist.broadcast(t, src=0)
+        return t
+    host = t.cpu()
+    dist.broadcast(host, src=0)
+    return host.to(t.device)
+
+
+def shard_check(job, args, world, rank, dist, backend, gens=4):
+    """The sharded job certifies itself on the box it was timed on (world > 1; collective).  Two comparisons, both BITWISE:
+
+    fitness  one generation's all-gathered fitness vector -- this rank's rollout of its own rows, ses_allgather_fitness over
+             the transport in force -- against rank 0's OWN rollout of the whole population, which it regenerates from
+             (parent, sigma, seed, generation): what `Pool.map` guarantees the reference (loop.py:66-79: every result, in
+             order), checked on every rank.
+    state    `gens` generations through the timed call (ESLoop.generations: on a library transport the device-side loop with
+             the exchanges inside the kernels) against rank 0's single-rank replay of the same generations from the same
+             snapshot (ses.parallel.solo): parent and Adam moments, and every rank against rank 0's.
+    """
+    import numpy as np
+    from ses import parallel
+    loop, strat = job.loop, job.loop.offspring_strategy
+    dev, n = loop.dev, job.n_global
+    t0 = time.perf_counter()
+    out = {"generations": gens, "offspring_total": n, "ranks": world,
+           "timed_path": "device-side loop (ses_run_generations)" if loop.device_side_loop else "per-generation calls"}
+    pop = job.pop
+    snap = strat.snapshot(pop)
+    # ---- fitness -------------------------------------------------------------------------------------------------
+    fit_all = loop.rollout(pop).clone()
+    fit_one = torch.empty_like(fit_all)
+    if rank == 0:
+        last = strat._last
+        idx = torch.from_numpy(np.ascontiguousarray(last["idx_host"], dtype=np.int32)).to(dev.device)
+        theta_all = strat.dev.perturb(last["parents"], last["sigma"], strat.seed, last["gen"], 0, n, parent_idx=idx)
+        with parallel.solo():
+            init = loop._init_states(pop.gen, parallel.Shard(n))
+        fit_one.copy_(dev.rollout(theta_all, init, mode=loop.mode))
+        loop._init_chunk = None                                    # (the resets of the whole population were drawn for this only)
+        del theta_all
+    torch.cuda.synchronize()
+    fit_one = _bcast_from_rank0(fit_one, dist, backend)
+    same_fit = bool(torch.equal(fit_all.view(torch.int32), fit_one.view(torch.int32)))
+    out["fitness_mismatches_this_rank"] = int((fit_all.view(torch.int32) != fit_one.view(torch.int32)).sum().item())
+    out["fitness_distinct_values"] = int(torch.unique(fit_one).numel())
+    # ---- state ---------------------------------------------------------------------------------------------------
+    job.generations(gens)
+    torch.cuda.synchronize()
+    mine = torch.cat([strat.mu_model.view(-1), strat.optimizer.m.view(-1), strat.optimizer.v.view(-1)]).clone()
+    ref = torch.empty_like(mine)
+    if rank == 0:
+        with parallel.solo():
+            solo = Job(args, n, 1, E=job.E)
+            solo.reset()
+            sstrat = solo.loop.offspring_strategy
+            solo.pop = sstrat.restore(snap)
+            solo.generations(gens)
+            torch.cuda.synchronize()
+            ref.copy_(torch.cat([sstrat.mu_model.view(-1), sstrat.optimizer.m.view(-1), sstrat.optimizer.v.view(-1)]))
+            out["solo_path"] = "device-side loop (ses_run_generations)" if solo.loop.device_side_loop else "per-generation calls"
+            del solo
+    torch.cuda.synchronize()
+    ref = _bcast_from_rank0(ref, dist, backend)
+    same_state = bool(torch.equal(mine.view(torch.int32), ref.view(torch.int32)))
+    out["state_mismatches_this_rank"] = int((mine.view(torch.int32) != ref.view(torch.int32)).sum().item())
+    out["state_nonzero"] = bool(ref.abs().sum().item() > 0)
+    out["fitness_bit_equal"] = parallel.all_ranks(same_fit, dev.device)
+    out["state_bit_equal"] = parallel.all_ranks(same_state, dev.device)
+    out["bit_equal"] = bool(out["fitness_bit_equal"] and out["state_bit_equal"])
+    out["seconds"] = time.perf_counter() - t0
+    out["what"] = ("fitness: one generation's all-gathered fitness == rank 0's own rollout of the whole population; state: parent + "
+                   "Adam moments after `generations` generations of the timed call == rank 0's single-rank replay from the same "
+                   "snapshot; both bitwise, true only if true on EVERY rank")
+    return out
+
+
+def rank0_legs(args, result, legs, job, es, world, E, T, skip):
+    """The legs only rank 0 runs (at n_gpus > 1 the peers wait at the final barrier meanwhile): per-kernel view of the headline
+    generation, BASELINE configs[2], the Box2D MLP configs, the env-step roofline, the one-rank RCCL round trip."""
+    # per-kernel view of one generation (rank 0, HIP events on the launch stream)
+    legs.begin("rollout_kernel")
+    pop = job.pop
+    init = es.init_states_uniform(0, 0, 0, 1, shared=True)[0]
+    samples = []
+    fit_buf = es.empty(pop.theta.shape[0])
+    for _ in range(20):
+        es.rollout(pop.theta, init, mode=job.loop.mode, fitness=fit_buf)
+    torch.cuda.synchronize()
+    for rep in range(9):                                   # median of 9 batches of 5 back-to-back ses_rollout calls
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(5):
+            es.rollout(pop.theta, init, mode=job.loop.mode, fitness=fit_buf)
+        ev[1].record()
+        ev[1].synchronize()
+        samples.append(ev[0].elapsed_time(ev[1]) / 5)
+    roll_ms = statistics.median(samples)
+    n_local = pop.theta.shape[0]
+    result["rollout_kernel"] = {"ms": roll_ms, "env_steps_per_s_one_gpu": n_local * E * T / (roll_ms * 1e-3),
+                                "includes": "the fused rollout kernel + the episode-mean kernel (one ses_rollout call; ~4.4 us of it is the mean kernel, "
+                                            "profiles/*_kernel_stats.csv has the rollout kernel alone)",
+                                "split": ("1024 waves x 4 envs at 16 lanes per env + 1024 waves x 16 envs at 4 lanes per env: one "
+                                          "light and one heavy wave, 20 envs, 244 VALU instructions per step on every SIMD "
+                                          "(chosen by the library's issue-cost model, csrc/ses_rollout.hip)"
+                                          if (n_local * E == 20480 and not args.gru) else "chosen by the library"),
+                                "bound": "valu-issue/latency (state and weights in VGPRs, no HBM traffic in the loop)",
+                                "mfma": "not used at eval_ep_num < 12: fp32 MFMA runs at the VALU rate and a 16-column "
+                                        "tile would be 5/16 full (profiles/r01_mfma_vs_valu_gru.txt)"}
+    if args.gru and E >= 12:
+        # the GRU rollout runs on v_mfma_f32_16x16x4_f32 from 12 episodes up: 2 fc1 + 96 gate + 8 fc2 tiles per
+        # step and 16-episode batch, 2048 flop per tile instruction (padding columns included), fp32 MFMA peak
+        # 157.3 TFLOP/s (MI355X_MICROARCH.md, Matrix cores)
+        flops = 106 * 2048.0 * n_local * ((E + 15) // 16) * T
+        result["rollout_kernel"].update({"bound": "fp32 mfma + valu (serial)", "mfma_tflops": flops / (roll_ms * 1e-3) / 1e12,
+                                         "mfma_peak_tflops": 157.3,
+                                         "mfma_frac": flops / (roll_ms * 1e-3) / 157.3e12,
+                                         "mfma": "v_mfma_f32_16x16x4_f32"})
+        # matrix-pipe busy fraction (rocprof's MfmaUtil) from the newest committed SQ profile of this kernel, attached
+        # only while the kernel's machine code is the profiled one
+        newest = None
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+            if name.endswith("_sq_gru_mfma.json"):
+                newest = os.path.join(ROOT, "profiles", name)
+        if newest:
+            sqm = json.load(open(newest))
+            now = kernel_code_hash("k_rollout_gru_mfma")
+            pd_ = sqm.get("per_dispatch", {})
+            if sqm.get("kernel_code_sha256") and now == sqm["kernel_code_sha256"] and pd_.get("GRBM_GUI_ACTIVE"):
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs, each with 128 SIMDs
+                result["rollout_kernel"]["mfma_util"] = pd_["SQ_VALU_MFMA_BUSY_CYCLES"] / (pd_["GRBM_GUI_ACTIVE"] * 128.0)
+                result["rollout_kernel"]["mfma_util_source"] = os.path.relpath(newest, ROOT)
+            else:
+                result["rollout_kernel"]["mfma_util_note"] = (f"{os.path.relpath(newest, ROOT)} was collected on different "
+                                                              "machine code of this kernel: not attached")
+    # VALU issue roofline of the rollout kernel: instruction count from the newest committed SQ counter profile of
+    # this same workload (attached only while the kernel's machine code is the profiled one), duration live
+    suffix, frag = ("_sq_gru_lockstep.json", "k_rollout_gru_lockstep") if args.gru else ("_sq_rollout.json", "k_rollout_cartpole_mlp")
+    sq = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+        if name.endswith(suffix):
+            sq = os.path.join(ROOT, "profiles", name)
+    if sq and n_local == 4096 and E == 5 and T == 500:
+        prof = json.load(open(sq))
+        now = kernel_code_hash(frag)
+        result["rollout_kernel"]["kernel_code_sha256"] = now
+        if not prof.get("kernel_code_sha256") or prof["kernel_code_sha256"] == now:
+            rate = prof["per_dispatch"]["SQ_INSTS_VALU"] / (roll_ms * 1e-3)
+            result["rollout_kernel"].update({"valu_wave_instr_per_dispatch": prof["per_dispatch"]["SQ_INSTS_VALU"],
+                                             "valu_wave_instr_per_s": rate,
+                                             "valu_issue_peak_per_s": prof["peak_valu_wave_instr_per_s"],
+                                             "valu_issue_frac": rate / prof["peak_valu_wave_instr_per_s"],
+                                             "valu_source": os.path.relpath(sq, ROOT)})
+        else:
+            result["rollout_kernel"]["valu_note"] = (f"{os.path.relpath(sq, ROOT)} was collected on different machine "
+                                                     "code of this kernel: not attached")
+        # the same duration against the serial-issue MODEL of the kernel's own instruction mix (tools/issue_model.py: every
+        # VALU instruction of the two loop bodies priced at its measured issue cadence): SIMD cycles the loops need over the
+        # SIMD cycles the kernel had.  valu_issue_frac above prices every instruction at the nominal 2 cycles.
+        models = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_issue_model.json"))
+        if models and not args.gru:
+            im = json.load(open(os.path.join(ROOT, "profiles", models[-1])))
+            if im.get("kernel_code_sha256") and im["kernel_code_sha256"] == now:
+                need = sum(v["waves"] * v["cycles"] for v in im["issue_cycles_per_step"].values()) * T
+                have = 1024 * roll_ms * 1e-3 * im["clock_ghz_under_load"] * 1e9
+                result["rollout_kernel"].update({
+                    "valu_issue_model_frac": need / have,
+                    "valu_issue_model": {k: v["cycles"] for k, v in im["issue_cycles_per_step"].items()},
+                    "valu_issue_model_source": os.path.join("profiles", models[-1]),
+                    "valu_issue_model_note": "SIMD cycles per env step of a light + a heavy wave if every VALU instruction issued alone "
+                                             "at its measured cadence (2 / 4 / 8 cycles), x steps, over duration x clock; the duration "
+                                             "includes the ~4.4 us episode-mean kernel"})
+            else:
+                result["rollout_kernel"]["valu_issue_model_note"] = (f"profiles/{models[-1]} prices different machine code of this "
+                                                                     "kernel (rerun tools/issue_model.py): not attached")
+    legs.end()
+    # BASELINE.json configs[2]: LunarLanderContinuous-v2 POMDP, GRU policy, 4096 offspring (conf/lunarlander_openai.yaml):
+    # one rollout of first-generation policies (sigma = init_sigma around the zero network), episodic
+    if not args.no_extras and not args.gru and "c3" not in skip:
+        legs.begin("c3_lunarlander")
+        try:
+            from ses import HipES
+            c3 = HipES("LunarLanderContinuous-v2", 8, 4, False, True, pomdp=True, max_step=300, eval_ep_num=5)
+            th = c3.perturb(c3.zeros(c3.P), 0.168, 0, 0, 0, 4096)
+            ini = c3.init_states_uniform(0, 0, 0, 4096)
+            fit3 = c3.empty(4096)
+            c3.rollout(th, ini, fitness=fit3)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                c3.rollout(th, ini, fitness=fit3)
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            _, _, st3 = c3.rollout(th, ini, want_episodes=True)
+            n3 = int(st3.sum().item())
+            ms3 = statistics.median(ts)
+            # the same population with the main-engine output biased on (fc2 bias of output 0 + 1.5): policies that
+            # fly instead of dropping -- what a trained population looks like to the kernel (long episodes)
+            thl = th.clone()
+            thl[:, c3.P - 4] += 1.5
+            c3.rollout(thl, ini, fitness=fit3)
+            torch.cuda.synchronize()
+            tl = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                c3.rollout(thl, ini, fitness=fit3)
+                e1.record()
+                e1.synchronize()
+                tl.append(e0.elapsed_time(e1))
+            _, _, stl = c3.rollout(thl, ini, want_episodes=True)
+            nl, msl = int(stl.sum().item()), statistics.median(tl)
+            # the floor of ANY schedule of this world step: the longest episode is a chain of dependent steps, and one env's
+            # step cannot take less than the latency of one world step on a wave that has its SIMD to itself (NOTES.md, "C3").
+            # Measured here: 64 envs = one wave, in flight (gentle main engine), the step-wise entry back to back.
+            lone = HipES("LunarLanderContinuous-v2", 8, 4, False, False, pomdp=True, max_step=300, eval_ep_num=1)
+            st_l, _ = lone.env_reset(lone.init_states_uniform(3, 0, 0, 64)[:, 0].contiguous())
+            up = torch.zeros(64, 4, device="cuda")
+            up[:, 0] = 0.3
+            for _ in range(5):
+                lone.env_step_generic(st_l, up)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(40):
+                lone.env_step_generic(st_l, up)
+            e1.record()
+            e1.synchronize()
+            lone_us = e0.elapsed_time(e1) * 1e3 / 40
+            lone.close()
+            longest3, longestl = int(st3.max().item()), int(stl.max().item())
+            result["c3_lunarlander_pomdp_gru_4096"] = {
+                "rollout_ms": ms3, "env_steps": n3, "env_steps_per_s": n3 / (ms3 * 1e-3), "mean_episode_steps": n3 / (4096 * 5),
+                "longest_episode_steps": longest3, "lone_wave_flight_step_us": lone_us,
+                "floor_ms": longest3 * lone_us * 1e-3, "frac_of_floor": longest3 * lone_us * 1e-3 / ms3,
+                "floor": "longest episode x the latency of one world step in flight on a wave alone on its SIMD (measured above with "
+                         "the step-wise entry, launch included; steps on the ground and the policy step cost more): no schedule of "
+                         "this world step finishes the population sooner, whatever its lane mapping",
+                "flying_policies": {"rollout_ms": msl, "env_steps": nl, "env_steps_per_s": nl / (msl * 1e-3),
+                                    "mean_episode_steps": nl / (4096 * 5), "longest_episode_steps": longestl,
+                                    "floor_ms": longestl * lone_us * 1e-3, "frac_of_floor": longestl * lone_us * 1e-3 / msl,
+                                    "note": "same population, main-engine bias + 1.5: long flights, what trained policies cost"},
+                "env": "gym's lunar_lander.py restated on a Box2D-style world: 3 bodies, 2 revolute joints, 180 velocity + "
+                       "<= 60 position iterations per step, time-of-impact sub-stepping against the terrain (parity with gym / Box2D unpinned; GPU == CPU build bit for bit)",
+                "bound": "valu issue + the latency of the sequential solver (profiles: *_sq_c3_lander.json)",
+                "parity": BOX2D_PARITY + "; returns vs the reference RolloutWorker + GRU over this env: crashing policies (G8) "
+                          "7.8e-6 relative, 2.3e-3 absolute; policies flying 300 steps / landing (G9) episode lengths equal, returns "
+                          "0.44 median / 4.9 max apart, inside the reference's own one-ulp sensitivity (0.55 / 8.6)"}
+            c3.close()
+        except Exception as exc:
+            result["c3_error"] = repr(exc)
+        legs.end()
+    # conf/bipedalwalker.yaml and conf/lunarlander.yaml at 4096 offspring x 5 episodes x <= 300 steps (MLP policies on the
+    # Box2D-style world, continuous collision on): one warm rollout, the median of two
+    if not args.no_extras and not args.gru and world == 1 and "box2d" not in skip:
+        legs.begin("box2d_mlp")
+        try:
+            from ses import HipES
+            legs = {}
+            for key, name, S in (("bipedalwalker_ms", "BipedalWalker-v3", 24), ("lunarlander_ms", "LunarLanderContinuous-v2", 8)):
+                bx = HipES(name, S, 4, False, False, max_step=300, eval_ep_num=5)
+                th = bx.perturb(bx.zeros(bx.P), 2.0, 0, 0, 0, 4096)
+                ini = bx.init_states_uniform(0, 0, 0, 4096)
+                fitb = bx.empty(4096)
+                bx.rollout(th, ini, fitness=fitb)
+                torch.cuda.synchronize()
+                tb = []
+                for _ in range(2):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    bx.rollout(th, ini, fitness=fitb)
+                    e1.record()
+                    e1.synchronize()
+                    tb.append(e0.elapsed_time(e1))
+                _, _, stb = bx.rollout(th, ini, want_episodes=True)
+                legs[key] = statistics.median(tb)
+                legs[key.replace("_ms", "_env_steps")] = int(stb.sum().item())
+                bx.close()
+            legs["parity"] = BOX2D_PARITY
+            legs["note"] = ("first-generation policies (sigma 2.0 around the zero network); parity with gym / Box2D unpinned, "
+                            "GPU == CPU build bit for bit; round 2: 455 / 42 ms")
+            result["box2d_mlp_4096"] = legs
+        except Exception as exc:
+            result["box2d_mlp_error"] = repr(exc)
+        legs.end()
+    if not args.no_roofline:
+        legs.begin("roofline")
+        try:
+            result["roofline"] = env_step_roofline(es, args.roofline_envs)
+            attach_traffic(result["roofline"], args.roofline_envs)
+        except Exception as exc:                                   # the headline line must still be printed
+            result["roofline_error"] = repr(exc)
+        legs.end()
+    if world == 1:
+        legs.begin("rccl_single_rank")
+        # the RCCL path of the library on this box: a one-rank communicator (ncclAllGather of one shard = a copy)
+        try:
+            from ses import HipES
+            solo = HipES(None, 4, 2, True, False)
+            solo.comm_init(0, 1, HipES.comm_unique_id())
+            shard_t = torch.rand(4096, device="cuda")
+            out = solo.allgather_fitness(shard_t)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                solo.allgather_fitness(shard_t, out=out)
+            e1.record()
+            e1.synchronize()
+            result["rccl_single_rank"] = {"rccl_version": solo.comm_info()[2], "ranks": 1, "bytes": 16384,
+                                          "allgather_us": e0.elapsed_time(e1) * 1e3 / 50,
+                                          "equal": bool(torch.equal(out, shard_t))}
+            solo.close()
+        except Exception as exc:
+            result["rccl_single_rank"] = {"error": repr(exc)}
+        legs.end()
 
 
 def run_rank(args):
@@ -362,11 +740,13 @@ def run_rank(args):
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    t_start = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
     backend = os.environ.get("SES_BENCH_BACKEND", "nccl")      # "gloo": test rigs where ranks share one GPU
+    skip = os.environ.get("SES_BENCH_SKIP", "")
     dist = None
     if args.rendezvous_only:
         import torch.distributed as dist
@@ -378,23 +758,53 @@ def run_rank(args):
             os.write(real_stdout, (json.dumps({"rendezvous": "ok", "world": world, "ranks": got}) + "\n").encode())
         dist.destroy_process_group()
         return 0
-    n_dev = torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()                            # (counts devices without creating a HIP context)
     if n_dev < 1 or (backend == "nccl" and n_dev < world):
         print(f"bench.py: rank {rank} sees {n_dev} GPU(s), {world} needed", file=sys.stderr)
         return 3
+    legs = Legs()
+    result = {}
+    # ---- the CPU baseline FIRST (N = 1, rank 0): ~15 s of host work during which the GPU has nothing to do; run before this
+    # process creates its HIP context, its worker pool forks a process that holds no GPU state, and the GPU legs that follow
+    # are one uninterrupted stretch for anybody who samples the device's activity from outside
+    if world == 1 and not args.no_cpu_baseline and "cpu_baseline" not in skip:
+        with legs.leg("cpu_baseline", gpu=False):
+            try:
+                from oracle import ref_port
+                result["cpu_baseline"] = ref_port.time_baseline()
+            except Exception as exc:
+                result["cpu_baseline_error"] = repr(exc)
     local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        # a collective that a failed rank never joins ends the run within minutes instead of hanging to the caller's limit
+        limit = datetime.timedelta(seconds=float(os.environ.get("SES_BENCH_PG_TIMEOUT_S", "240")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def collective_leg(fn):
+        """Run fn() -- a leg with collectives inside -- and make its OUTCOME collective: if it raised on any rank, every rank
+        records an error for the leg (a rank that carried on alone would sit in the next leg's barrier until the time-out).
+        A failure on some ranks only, inside a collective, still strands the others in it: the process group's time-out
+        (SES_BENCH_PG_TIMEOUT_S) then ends the run."""
+        from ses.parallel import all_ranks
+        err = None
+        try:
+            rec = fn()
+        except Exception as exc:
+            rec, err = None, repr(exc)
+        if world > 1 and not all_ranks(err is None, torch.device("cuda", local_rank)):
+            return {"error": err or "failed on another rank"}
+        return rec if err is None else {"error": err}
 
     E, T = args.eval_ep_num, args.max_step
     work = tempfile.mkdtemp(prefix="ses_bench_")               # ESLoop writes logs/<env>/<stamp>/ under the cwd
@@ -403,19 +813,20 @@ def run_rank(args):
 
     # ---- headline: BASELINE's metric as written -- 4096 offspring IN TOTAL, sharded over the GPUs (strong scaling; at one GPU
     # this is also the weak job).  The weak reading (4096 per GPU) and BASELINE configs[3] (65 536 in total) are timed below.
-    job = Job(args, args.offspring_per_gpu, world)
-    job.reset()
-    job.generations(preroll)                                   # clock ramp; a generation is ~0.25 ms
-    job.reset()                                                # the measured run starts from the zero network
-    job.generations(args.warmup)
-    c0 = exchange_counts(job)
-    times = timed_blocks(job, args.steps, max(args.blocks, 1), barrier, dist, world)
-    c1 = exchange_counts(job)
-    head = summarise(job, args.steps, times)
+    with legs.leg("headline"):
+        job = Job(args, args.offspring_total, world)
+        job.reset()
+        job.generations(preroll)                                   # clock ramp; a generation is ~0.25 ms
+        job.reset()                                                # the measured run starts from the zero network
+        job.generations(args.warmup)
+        c0 = exchange_counts(job)
+        times = timed_blocks(job, args.steps, max(args.blocks, 1), barrier, dist, world, min_seconds=args.min_timed_seconds)
+        c1 = exchange_counts(job)
+        head = summarise(job, args.steps, times)
     if c0 is not None and c1 is not None:
         # what carried the two exchanges of a generation during the timed blocks: launches of ses_allgather_fitness / exchanges the
         # kernels did themselves with granules (the fitness inside ses_run_generations above 8192 rows, the chunk partials)
-        gens = args.steps * max(args.blocks, 1)
+        gens = args.steps * len(times)
         head["exchanges_per_generation"] = {"allgather_launches": (c1[0] - c0[0]) / gens, "granule_exchanges": (c1[1] - c0[1]) / gens}
     from ses.parallel import comm_info, comm_transport
     comm_rank, comm_world, rccl_version = comm_info(job.loop.dev)
@@ -423,23 +834,30 @@ def run_rank(args):
     head.update(job.phases())
     head["rccl_ranks"] = comm_world
     head["allgather_transport"] = transport
+    if world > 1:
+        with legs.leg("headline_shard_check"):
+            head["shard_check"] = collective_leg(lambda: shard_check(job, args, world, rank, dist, backend))
 
-    result = {
+    result.update({
         "metric": METRIC, "value": head["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "ms_per_step_min": head["ms_per_step_min"],
-        "ms_per_step_max": head["ms_per_step_max"], "blocks": head["blocks"],
+        "ms_per_step_max": head["ms_per_step_max"], "blocks": head["blocks"], "timed_seconds": head["timed_seconds"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("POMDP CartPole-v1 openai_es GRU(4-32-GRU32-2, P=6562)" if args.gru else
                                 "CartPole-v1 openai_es MLP(4-32-2, P=226)") + ", fixed-length episodes, termination masked",
                    "timed_call": ("ESLoop.generations(steps): the product loop's own enqueue path -- ses_run_generations in chunks of <= 32 "
                                   "generations, the fitness all-gather issued by the C loop" if job.loop.batched_generations or
-                                  getattr(job.loop, "_bench_batch", None) else
+                                  job.loop.device_side_loop else
                                   "ESLoop.generation() x steps (the product loop's per-generation method), openai_es strategy object"),
                    "value_is": ("whole-job env-steps/s of the metric AS WRITTEN: 4096 offspring in total, sharded over n_gpus (strong "
                                 "scaling: per-GPU work shrinks as n_gpus grows; a 0.2 ms generation of 500 dependent env steps cannot "
                                 "shrink much).  Beside it: weak_4096_per_gpu.value (4096 offspring PER GPU, offspring_total = 4096 x "
                                 "n_gpus) and c4_65536_total.value (BASELINE configs[3]); each with a *_rccl twin timed with the "
                                 "exchanges forced onto ncclAllGather.  At n_gpus = 1 the first two coincide"),
+                   "headline_definition_changed_in": ("r05: `value` at n_gpus > 1 is the STRONG job (offspring_total fixed at 4096); rounds "
+                                                      "1-4 printed the weak job there (4096 per GPU, now weak_4096_per_gpu.value).  At "
+                                                      "n_gpus = 1 nothing changed.  r06: --offspring-total sets the headline's "
+                                                      "population, --offspring-per-gpu only the weak leg's"),
                    "offspring_per_gpu": -(-job.n_global // world), "offspring_total": job.n_global, "eval_ep_num": E,
                    "max_step": T, "env_steps_per_generation": job.steps_per_generation(),
                    "noise": "rocRAND philox4x32_10", "preroll_generations": preroll,
@@ -450,39 +868,47 @@ def run_rank(args):
                                     "torch": f"FALLBACK torch.distributed/{backend} (no library transport could be set up)"}[transport])},
         "parity": PARITY_NOTE,
         "strong_4096_total": head,
-    }
-    if world == 1:
+    })
+    if world == 1 and args.offspring_total == args.offspring_per_gpu:
         result["weak_4096_per_gpu"] = dict(head, note="same job as strong_4096_total at 1 GPU")
 
     def rccl_twin(j, steps_, blocks_):
         """The same job with every exchange of a generation forced onto RCCL (ncclAllGather on the handle's stream: the fitness
         shards, and the chunk partials of the shard form of the tail) through the same ESLoop.generations -> ses_run_generations
-        path.  "absent" where no communicator spans the ranks (rigs whose ranks share a GPU)."""
+        path.  "absent" where no communicator spans the ranks (rigs whose ranks share a GPU).  The twin certifies itself like
+        its job (shard_check, with the exchanges on RCCL) and asserts that its communicator spans all the ranks."""
         owner = getattr(j.loop.dev, "_comm_owner", None)
-        if world == 1 or owner is None or owner.comm_route()[2] != world:
+        if world == 1 or owner is None or owner.comm_route()[2] != world:      # (the same answer on every rank: attach_comm agreed)
             return "absent"
-        try:
-            owner.set_tuning("comm_force_rccl", 1)
-            j.generations(30)
-            rec = summarise(j, steps_, timed_blocks(j, steps_, blocks_, barrier, dist, world))
-            rec.update(j.phases())
-            rec["allgather_transport"] = "rccl (forced)"
-            rec["rccl_ranks"] = comm_info(j.loop.dev)[1]
-            return rec
-        except Exception as exc:
-            return {"error": repr(exc)}
-        finally:
-            owner.set_tuning("comm_force_rccl", 0)
 
-    result["strong_4096_total_rccl"] = rccl_twin(job, min(args.steps, 100), 7)
+        def body():
+            owner.set_tuning("comm_force_rccl", 1)
+            try:
+                ranks = comm_info(j.loop.dev)[1]
+                if ranks != world:
+                    raise RuntimeError(f"the RCCL communicator spans {ranks} ranks, the job {world}")
+                j.generations(30)
+                rec = summarise(j, steps_, timed_blocks(j, steps_, blocks_, barrier, dist, world))
+                rec.update(j.phases())
+                rec["allgather_transport"] = "rccl (forced)"
+                rec["rccl_ranks"] = ranks
+                rec["shard_check"] = shard_check(j, args, world, rank, dist, backend)
+                return rec
+            finally:
+                owner.set_tuning("comm_force_rccl", 0)
+        return collective_leg(body)
+
+    with legs.leg("headline_rccl"):
+        result["strong_4096_total_rccl"] = rccl_twin(job, min(args.steps, 100), 7)
 
     # ---- the two other readings of the metric ------------------------------------------------------------------------
     if not args.no_extras:
         x_steps, x_blocks = min(args.steps, 100), 7
         for key, n_total in (("weak_4096_per_gpu", args.offspring_per_gpu * world), ("c4_65536_total", 65536)):
-            if key in os.environ.get("SES_BENCH_SKIP", "") or key in result:
+            if key in skip or key in result:
                 continue
-            try:
+
+            def extra_job(n_total=n_total):
                 j = Job(args, n_total, world)
                 j.reset()
                 j.generations(30)
@@ -496,18 +922,23 @@ def run_rank(args):
                 rec.update(j.phases())
                 rec["rccl_ranks"] = comm_info(j.loop.dev)[1]
                 rec["allgather_transport"] = comm_transport(j.loop.dev, -(-n_total // world)) if world > 1 else "none"
-                result[key] = rec
-                result[key + "_rccl"] = rccl_twin(j, x_steps, x_blocks)
+                if world > 1:
+                    rec["shard_check"] = shard_check(j, args, world, rank, dist, backend)
+                return rec, j
+            with legs.leg(key):
+                got = collective_leg(extra_job)                          # the headline line must still be printed
+            if isinstance(got, tuple):
+                result[key], j = got
+                with legs.leg(key + "_rccl"):
+                    result[key + "_rccl"] = rccl_twin(j, x_steps, x_blocks)
                 del j
-            except Exception as exc:                                 # the headline line must still be printed
-                result[key] = {"error": repr(exc)}
+            else:
+                result[key] = got
 
         # ---- the same job with ONE episode per offspring (--eval-ep-num 1; the reference's default is 5, run_es.py:33-38) ----
-        if E != 1 and "e1" not in os.environ.get("SES_BENCH_SKIP", ""):
-            try:
-                a1 = argparse.Namespace(**vars(args))
-                a1.eval_ep_num = 1
-                j = Job(a1, args.offspring_per_gpu * world, world)
+        if E != 1 and "e1" not in skip:
+            def e1_job():
+                j = Job(args, args.offspring_per_gpu * world, world, E=1)
                 j.reset()
                 j.generations(60)
                 rec = summarise(j, x_steps, timed_blocks(j, x_steps, x_blocks, barrier, dist, world))
@@ -516,329 +947,106 @@ def run_rank(args):
                 rec["env_steps_per_generation"] = j.steps_per_generation()
                 rec["note"] = ("4096 envs per GPU instead of 20 480: a fifth of the rollout work against the same per-generation tail "
                                "(rank, gradient, update, perturbation), so fewer env-steps/s than the E = 5 line of record")
-                result["e1"] = rec
-                del j
-            except Exception as exc:
-                result["e1"] = {"error": repr(exc)}
+                return rec
+            with legs.leg("e1"):
+                result["e1"] = collective_leg(e1_job)
 
         # ---- the loop a user runs: ESLoop.run() with its prints and metrics.jsonl ------------------------------------
         # Two fresh loops of different length; the per-generation figure is the difference quotient, so that what a
         # new loop spends once (handles, scratch, allocator warm-up: `loop_startup_ms`) is not smeared over it.
-        try:
-            import builder
-            gens = args.loop_generations if args.steps >= 100 else min(args.loop_generations, 300)
-            short = max(gens // 5, 20)
-            took = []
-            # the first run is untimed: the first LONG ESLoop.run() of a process takes ~40 ms more than every later one
-            # (measured: 349.6 vs 310.4 ms for 1200 generations, whatever ran before; a one-time cost of the runtime, not
-            # of the loop), which a 1000-generation window would report as +15 % per generation
-            for g in (short + gens, short, short + gens):
-                loop = builder.build_loop(job.cfg, g, 1, E, False, 10 ** 9)
-                job.generations(150)                                     # building a loop is host work: clocks back up
-                barrier()
-                t0 = time.perf_counter()
-                with open(os.devnull, "w") as sink, contextlib.redirect_stdout(sink):
-                    loop.run()
-                barrier()
-                took.append(time.perf_counter() - t0)
-                del loop
-            result["loop_first_long_run_ms"] = took.pop(0) * 1e3
-            per = (took[1] - took[0]) / gens
-            result["loop_ms_per_generation"] = per * 1e3
-            result["loop_generations"] = gens
-            result["loop_startup_ms"] = (took[0] - short * per) * 1e3
-            result["loop_vs_step"] = result["loop_ms_per_generation"] / result["ms_per_step"]
-        except Exception as exc:
-            result["loop_error"] = repr(exc)
-
-    es = job.loop.dev
-    if rank == 0:
-        # per-kernel view of one generation (rank 0, HIP events on the launch stream)
-        pop = job.pop
-        init = es.init_states_uniform(0, 0, 0, 1, shared=True)[0]
-        samples = []
-        fit_buf = es.empty(pop.theta.shape[0])
-        for _ in range(20):
-            es.rollout(pop.theta, init, mode=job.loop.mode, fitness=fit_buf)
-        torch.cuda.synchronize()
-        for rep in range(9):                                   # median of 9 batches of 5 back-to-back ses_rollout calls
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            ev[0].record()
-            for _ in range(5):
-                es.rollout(pop.theta, init, mode=job.loop.mode, fitness=fit_buf)
-            ev[1].record()
-            ev[1].synchronize()
-            samples.append(ev[0].elapsed_time(ev[1]) / 5)
-        roll_ms = statistics.median(samples)
-        n_local = pop.theta.shape[0]
-        result["rollout_kernel"] = {"ms": roll_ms, "env_steps_per_s_one_gpu": n_local * E * T / (roll_ms * 1e-3),
-                                    "includes": "the fused rollout kernel + the episode-mean kernel (one ses_rollout call; ~4.4 us of it is the mean kernel, "
-                                                "profiles/*_kernel_stats.csv has the rollout kernel alone)",
-                                    "split": ("1024 waves x 4 envs at 16 lanes per env + 1024 waves x 16 envs at 4 lanes per env: one "
-                                              "light and one heavy wave, 20 envs, 244 VALU instructions per step on every SIMD "
-                                              "(chosen by the library's issue-cost model, csrc/ses_rollout.hip)"
-                                              if (n_local * E == 20480 and not args.gru) else "chosen by the library"),
-                                    "bound": "valu-issue/latency (state and weights in VGPRs, no HBM traffic in the loop)",
-                                    "mfma": "not used at eval_ep_num < 12: fp32 MFMA runs at the VALU rate and a 16-column "
-                                            "tile would be 5/16 full (profiles/r01_mfma_vs_valu_gru.txt)"}
-        if args.gru and E >= 12:
-            # the GRU rollout runs on v_mfma_f32_16x16x4_f32 from 12 episodes up: 2 fc1 + 96 gate + 8 fc2 tiles per
-            # step and 16-episode batch, 2048 flop per tile instruction (padding columns included), fp32 MFMA peak
-            # 157.3 TFLOP/s (MI355X_MICROARCH.md, Matrix cores)
-            flops = 106 * 2048.0 * n_local * ((E + 15) // 16) * T
-            result["rollout_kernel"].update({"bound": "fp32 mfma + valu (serial)", "mfma_tflops": flops / (roll_ms * 1e-3) / 1e12,
-                                             "mfma_peak_tflops": 157.3,
-                                             "mfma_frac": flops / (roll_ms * 1e-3) / 157.3e12,
-                                             "mfma": "v_mfma_f32_16x16x4_f32"})
-            # matrix-pipe busy fraction (rocprof's MfmaUtil) from the newest committed SQ profile of this kernel, attached
-            # only while the kernel's machine code is the profiled one
-            newest = None
-            for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
-                if name.endswith("_sq_gru_mfma.json"):
-                    newest = os.path.join(ROOT, "profiles", name)
-            if newest:
-                sqm = json.load(open(newest))
-                now = kernel_code_hash("k_rollout_gru_mfma")
-                pd_ = sqm.get("per_dispatch", {})
-                if sqm.get("kernel_code_sha256") and now == sqm["kernel_code_sha256"] and pd_.get("GRBM_GUI_ACTIVE"):
-                    # GRBM_GUI_ACTIVE is summed over the 8 XCDs, each with 128 SIMDs
-                    result["rollout_kernel"]["mfma_util"] = pd_["SQ_VALU_MFMA_BUSY_CYCLES"] / (pd_["GRBM_GUI_ACTIVE"] * 128.0)
-                    result["rollout_kernel"]["mfma_util_source"] = os.path.relpath(newest, ROOT)
-                else:
-                    result["rollout_kernel"]["mfma_util_note"] = (f"{os.path.relpath(newest, ROOT)} was collected on different "
-                                                                  "machine code of this kernel: not attached")
-        # VALU issue roofline of the rollout kernel: instruction count from the newest committed SQ counter profile of
-        # this same workload (attached only while the kernel's machine code is the profiled one), duration live
-        suffix, frag = ("_sq_gru_lockstep.json", "k_rollout_gru_lockstep") if args.gru else ("_sq_rollout.json", "k_rollout_cartpole_mlp")
-        sq = None
-        for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
-            if name.endswith(suffix):
-                sq = os.path.join(ROOT, "profiles", name)
-        if sq and n_local == 4096 and E == 5 and T == 500:
-            prof = json.load(open(sq))
-            now = kernel_code_hash(frag)
-            result["rollout_kernel"]["kernel_code_sha256"] = now
-            if not prof.get("kernel_code_sha256") or prof["kernel_code_sha256"] == now:
-                rate = prof["per_dispatch"]["SQ_INSTS_VALU"] / (roll_ms * 1e-3)
-                result["rollout_kernel"].update({"valu_wave_instr_per_dispatch": prof["per_dispatch"]["SQ_INSTS_VALU"],
-                                                 "valu_wave_instr_per_s": rate,
-                                                 "valu_issue_peak_per_s": prof["peak_valu_wave_instr_per_s"],
-                                                 "valu_issue_frac": rate / prof["peak_valu_wave_instr_per_s"],
-                                                 "valu_source": os.path.relpath(sq, ROOT)})
+        if "loop" not in skip:
+            def loop_leg():
+                import builder
+                gens = args.loop_generations if args.steps >= 100 else min(args.loop_generations, 300)
+                short = max(gens // 5, 20)
+                took = []
+                # the first run is untimed: the first LONG ESLoop.run() of a process takes ~40 ms more than every later one
+                # (measured: 349.6 vs 310.4 ms for 1200 generations, whatever ran before; a one-time cost of the runtime, not
+                # of the loop), which a 1000-generation window would report as +15 % per generation
+                for g in (short + gens, short, short + gens):
+                    loop = builder.build_loop(job.cfg, g, 1, E, False, 10 ** 9)
+                    job.generations(150)                                     # building a loop is host work: clocks back up
+                    barrier()
+                    t0 = time.perf_counter()
+                    with open(os.devnull, "w") as sink, contextlib.redirect_stdout(sink):
+                        loop.run()
+                    barrier()
+                    took.append(time.perf_counter() - t0)
+                    del loop
+                first = took.pop(0) * 1e3
+                per = (took[1] - took[0]) / gens
+                return {"loop_first_long_run_ms": first, "loop_ms_per_generation": per * 1e3, "loop_generations": gens,
+                        "loop_startup_ms": (took[0] - short * per) * 1e3, "loop_vs_step": per * 1e3 / result["ms_per_step"]}
+            with legs.leg("loop"):
+                rec = collective_leg(loop_leg)
+            if "error" in rec:
+                result["loop_error"] = rec["error"]
             else:
-                result["rollout_kernel"]["valu_note"] = (f"{os.path.relpath(sq, ROOT)} was collected on different machine "
-                                                         "code of this kernel: not attached")
-            # the same duration against the serial-issue MODEL of the kernel's own instruction mix (tools/issue_model.py: every
-            # VALU instruction of the two loop bodies priced at its measured issue cadence): SIMD cycles the loops need over the
-            # SIMD cycles the kernel had.  valu_issue_frac above prices every instruction at the nominal 2 cycles.
-            models = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_issue_model.json"))
-            if models and not args.gru:
-                im = json.load(open(os.path.join(ROOT, "profiles", models[-1])))
-                if im.get("kernel_code_sha256") and im["kernel_code_sha256"] == now:
-                    need = sum(v["waves"] * v["cycles"] for v in im["issue_cycles_per_step"].values()) * T
-                    have = 1024 * roll_ms * 1e-3 * im["clock_ghz_under_load"] * 1e9
-                    result["rollout_kernel"].update({
-                        "valu_issue_model_frac": need / have,
-                        "valu_issue_model": {k: v["cycles"] for k, v in im["issue_cycles_per_step"].items()},
-                        "valu_issue_model_source": os.path.join("profiles", models[-1]),
-                        "valu_issue_model_note": "SIMD cycles per env step of a light + a heavy wave if every VALU instruction issued alone "
-                                                 "at its measured cadence (2 / 4 / 8 cycles), x steps, over duration x clock; the duration "
-                                                 "includes the ~4.4 us episode-mean kernel"})
-                else:
-                    result["rollout_kernel"]["valu_issue_model_note"] = (f"profiles/{models[-1]} prices different machine code of this "
-                                                                         "kernel (rerun tools/issue_model.py): not attached")
-        # BASELINE.json configs[2]: LunarLanderContinuous-v2 POMDP, GRU policy, 4096 offspring (conf/lunarlander_openai.yaml):
-        # one rollout of first-generation policies (sigma = init_sigma around the zero network), episodic
-        if not args.no_extras and not args.gru:
-            try:
-                from ses import HipES
-                c3 = HipES("LunarLanderContinuous-v2", 8, 4, False, True, pomdp=True, max_step=300, eval_ep_num=5)
-                th = c3.perturb(c3.zeros(c3.P), 0.168, 0, 0, 0, 4096)
-                ini = c3.init_states_uniform(0, 0, 0, 4096)
-                fit3 = c3.empty(4096)
-                c3.rollout(th, ini, fitness=fit3)
-                torch.cuda.synchronize()
-                ts = []
-                for _ in range(3):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    c3.rollout(th, ini, fitness=fit3)
-                    e1.record()
-                    e1.synchronize()
-                    ts.append(e0.elapsed_time(e1))
-                _, _, st3 = c3.rollout(th, ini, want_episodes=True)
-                n3 = int(st3.sum().item())
-                ms3 = statistics.median(ts)
-                # the same population with the main-engine output biased on (fc2 bias of output 0 + 1.5): policies that
-                # fly instead of dropping -- what a trained population looks like to the kernel (long episodes)
-                thl = th.clone()
-                thl[:, c3.P - 4] += 1.5
-                c3.rollout(thl, ini, fitness=fit3)
-                torch.cuda.synchronize()
-                tl = []
-                for _ in range(3):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    c3.rollout(thl, ini, fitness=fit3)
-                    e1.record()
-                    e1.synchronize()
-                    tl.append(e0.elapsed_time(e1))
-                _, _, stl = c3.rollout(thl, ini, want_episodes=True)
-                nl, msl = int(stl.sum().item()), statistics.median(tl)
-                # the floor of ANY schedule of this world step: the longest episode is a chain of dependent steps, and one env's
-                # step cannot take less than the latency of one world step on a wave that has its SIMD to itself (NOTES.md, "C3").
-                # Measured here: 64 envs = one wave, in flight (gentle main engine), the step-wise entry back to back.
-                lone = HipES("LunarLanderContinuous-v2", 8, 4, False, False, pomdp=True, max_step=300, eval_ep_num=1)
-                st_l, _ = lone.env_reset(lone.init_states_uniform(3, 0, 0, 64)[:, 0].contiguous())
-                up = torch.zeros(64, 4, device="cuda")
-                up[:, 0] = 0.3
-                for _ in range(5):
-                    lone.env_step_generic(st_l, up)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(40):
-                    lone.env_step_generic(st_l, up)
-                e1.record()
-                e1.synchronize()
-                lone_us = e0.elapsed_time(e1) * 1e3 / 40
-                lone.close()
-                longest3, longestl = int(st3.max().item()), int(stl.max().item())
-                result["c3_lunarlander_pomdp_gru_4096"] = {
-                    "rollout_ms": ms3, "env_steps": n3, "env_steps_per_s": n3 / (ms3 * 1e-3), "mean_episode_steps": n3 / (4096 * 5),
-                    "longest_episode_steps": longest3, "lone_wave_flight_step_us": lone_us,
-                    "floor_ms": longest3 * lone_us * 1e-3, "frac_of_floor": longest3 * lone_us * 1e-3 / ms3,
-                    "floor": "longest episode x the latency of one world step in flight on a wave alone on its SIMD (measured above with "
-                             "the step-wise entry, launch included; steps on the ground and the policy step cost more): no schedule of "
-                             "this world step finishes the population sooner, whatever its lane mapping",
-                    "flying_policies": {"rollout_ms": msl, "env_steps": nl, "env_steps_per_s": nl / (msl * 1e-3),
-                                        "mean_episode_steps": nl / (4096 * 5), "longest_episode_steps": longestl,
-                                        "floor_ms": longestl * lone_us * 1e-3, "frac_of_floor": longestl * lone_us * 1e-3 / msl,
-                                        "note": "same population, main-engine bias + 1.5: long flights, what trained policies cost"},
-                    "env": "gym's lunar_lander.py restated on a Box2D-style world: 3 bodies, 2 revolute joints, 180 velocity + "
-                           "<= 60 position iterations per step, time-of-impact sub-stepping against the terrain (parity with gym / Box2D unpinned; GPU == CPU build bit for bit)",
-                    "bound": "valu issue + the latency of the sequential solver (profiles: *_sq_c3_lander.json)",
-                    "parity": BOX2D_PARITY + "; returns vs the reference RolloutWorker + GRU over this env: crashing policies (G8) "
-                              "7.8e-6 relative, 2.3e-3 absolute; policies flying 300 steps / landing (G9) episode lengths equal, returns "
-                              "0.44 median / 4.9 max apart, inside the reference's own one-ulp sensitivity (0.55 / 8.6)"}
-                c3.close()
-            except Exception as exc:
-                result["c3_error"] = repr(exc)
-        # conf/bipedalwalker.yaml and conf/lunarlander.yaml at 4096 offspring x 5 episodes x <= 300 steps (MLP policies on the
-        # Box2D-style world, continuous collision on): one warm rollout, the median of two
-        if not args.no_extras and not args.gru and world == 1:
-            try:
-                from ses import HipES
-                legs = {}
-                for key, name, S in (("bipedalwalker_ms", "BipedalWalker-v3", 24), ("lunarlander_ms", "LunarLanderContinuous-v2", 8)):
-                    bx = HipES(name, S, 4, False, False, max_step=300, eval_ep_num=5)
-                    th = bx.perturb(bx.zeros(bx.P), 2.0, 0, 0, 0, 4096)
-                    ini = bx.init_states_uniform(0, 0, 0, 4096)
-                    fitb = bx.empty(4096)
-                    bx.rollout(th, ini, fitness=fitb)
-                    torch.cuda.synchronize()
-                    tb = []
-                    for _ in range(2):
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                        bx.rollout(th, ini, fitness=fitb)
-                        e1.record()
-                        e1.synchronize()
-                        tb.append(e0.elapsed_time(e1))
-                    _, _, stb = bx.rollout(th, ini, want_episodes=True)
-                    legs[key] = statistics.median(tb)
-                    legs[key.replace("_ms", "_env_steps")] = int(stb.sum().item())
-                    bx.close()
-                legs["parity"] = BOX2D_PARITY
-                legs["note"] = ("first-generation policies (sigma 2.0 around the zero network); parity with gym / Box2D unpinned, "
-                                "GPU == CPU build bit for bit; round 2: 455 / 42 ms")
-                result["box2d_mlp_4096"] = legs
-            except Exception as exc:
-                result["box2d_mlp_error"] = repr(exc)
-        if not args.no_roofline:
-            try:
-                result["roofline"] = env_step_roofline(es, args.roofline_envs)
-                attach_traffic(result["roofline"], args.roofline_envs)
-            except Exception as exc:                                   # the headline line must still be printed
-                result["roofline_error"] = repr(exc)
-        if world == 1:
-            # the RCCL path of the library on this box: a one-rank communicator (ncclAllGather of one shard = a copy)
-            try:
-                from ses import HipES
-                solo = HipES(None, 4, 2, True, False)
-                solo.comm_init(0, 1, HipES.comm_unique_id())
-                shard_t = torch.rand(4096, device="cuda")
-                out = solo.allgather_fitness(shard_t)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(50):
-                    solo.allgather_fitness(shard_t, out=out)
-                e1.record()
-                e1.synchronize()
-                result["rccl_single_rank"] = {"rccl_version": solo.comm_info()[2], "ranks": 1, "bytes": 16384,
-                                              "allgather_us": e0.elapsed_time(e1) * 1e3 / 50,
-                                              "equal": bool(torch.equal(out, shard_t))}
-                solo.close()
-            except Exception as exc:
-                result["rccl_single_rank"] = {"error": repr(exc)}
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                from oracle import ref_port
-                result["cpu_baseline"] = ref_port.time_baseline()
-            except Exception as exc:
-                result["cpu_baseline_error"] = repr(exc)
+                result.update(rec)
+
     if world > 1:
         # ---- the exchange alone, both transports, every rank in step: 16 KB and 128 KB per rank ------------------------
-        try:
+        # (before the rank-0-only legs below, during which the peers have nothing to do)
+        def micro_leg():
             owner = getattr(job.loop.dev, "_comm_owner", None)
             micro = {}
             have_p2p = owner is not None and owner.comm_route()[0] == world
             have_rccl = owner is not None and owner.comm_route()[2] == world
             for label, floats in (("16KB", 4096), ("128KB", 32768)):
                 micro[label] = {"p2p_store_us": "absent", "p2p_store_granules_us": "absent", "rccl_us": "absent"}   # a transport that could not be set up says so
-            if owner is not None:
-                for label, floats in (("16KB", 4096), ("128KB", 32768)):
-                    shard_t = torch.full((floats,), float(rank), device=owner.device)
-                    out_t = owner.empty(world * floats)
-                    # p2p_store_us: the default kernel (data + sequence words, release / acquire); p2p_store_granules_us: 8-byte
-                    # {exchange number, value} granules, the data as its own flag (knob "comm_granule_allgather")
-                    for name, on, force, gran in (("p2p_store_us", have_p2p, 0, 0), ("p2p_store_granules_us", have_p2p, 0, 1),
-                                                  ("rccl_us", have_rccl, 1, 0)):
-                        if not on:
-                            continue
-                        owner.set_tuning("comm_force_rccl", force)
-                        owner.set_tuning("comm_granule_allgather", gran)
-                        for _ in range(10):
-                            owner.allgather_fitness(shard_t, out=out_t)
-                        torch.cuda.synchronize(); dist.barrier()
-                        with torch.cuda.stream(owner.stream):
-                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                            e0.record()
-                            for _ in range(100):
+            try:
+                if owner is not None:
+                    for label, floats in (("16KB", 4096), ("128KB", 32768)):
+                        shard_t = torch.full((floats,), float(rank), device=owner.device)
+                        out_t = owner.empty(world * floats)
+                        # p2p_store_us: the default kernel (data + sequence words, release / acquire); p2p_store_granules_us: 8-byte
+                        # {exchange number, value} granules, the data as its own flag (knob "comm_granule_allgather")
+                        for name, on, force, gran in (("p2p_store_us", have_p2p, 0, 0), ("p2p_store_granules_us", have_p2p, 0, 1),
+                                                      ("rccl_us", have_rccl, 1, 0)):
+                            if not on:
+                                continue
+                            owner.set_tuning("comm_force_rccl", force)
+                            owner.set_tuning("comm_granule_allgather", gran)
+                            for _ in range(10):
                                 owner.allgather_fitness(shard_t, out=out_t)
-                            e1.record()
-                        e1.synchronize()
-                        t = torch.tensor([e0.elapsed_time(e1) * 10.0], device=owner.device)
-                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                        ok = bool(torch.equal(out_t.view(world, floats)[:, 0].cpu(), torch.arange(world, dtype=torch.float32)))
-                        micro[label][name] = round(float(t.item()), 2)
-                        micro[label]["correct"] = micro[label].get("correct", True) and ok
+                            torch.cuda.synchronize(); dist.barrier()
+                            with torch.cuda.stream(owner.stream):
+                                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                                e0.record()
+                                for _ in range(100):
+                                    owner.allgather_fitness(shard_t, out=out_t)
+                                e1.record()
+                            e1.synchronize()
+                            t = torch.tensor([e0.elapsed_time(e1) * 10.0], device=owner.device)
+                            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                            ok = bool(torch.equal(out_t.view(world, floats)[:, 0].cpu(), torch.arange(world, dtype=torch.float32)))
+                            micro[label][name] = round(float(t.item()), 2)
+                            micro[label]["correct"] = micro[label].get("correct", True) and ok
+            finally:                                                   # whatever happened above, the transport is left as it was found
+                if owner is not None:
                     owner.set_tuning("comm_force_rccl", 0)
                     owner.set_tuning("comm_granule_allgather", 0)
-            result["allgather_microbench"] = dict(micro, ranks=world, transports={"p2p_store": "attached" if have_p2p else "absent",
-                                                                                    "rccl": "attached" if have_rccl else "absent"},
-                                                  note="100 back-to-back ses_allgather_fitness per transport, max over ranks, us per exchange")
-        except Exception as exc:
-            result["allgather_microbench"] = {"error": repr(exc)}
-        finally:                                                       # whatever happened above, the transport is left as it was found
-            owner = getattr(job.loop.dev, "_comm_owner", None)
-            if owner is not None:
-                owner.set_tuning("comm_force_rccl", 0)
-                owner.set_tuning("comm_granule_allgather", 0)
+            return dict(micro, ranks=world, transports={"p2p_store": "attached" if have_p2p else "absent",
+                                                        "rccl": "attached" if have_rccl else "absent"},
+                        note="100 back-to-back ses_allgather_fitness per transport, max over ranks, us per exchange")
+        with legs.leg("allgather_microbench"):
+            result["allgather_microbench"] = collective_leg(micro_leg)
+
+    es = job.loop.dev
+    if rank == 0:
+        rank0_legs(args, result, legs, job, es, world, E, T, skip)
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        result["legs_wall_s"] = {k: round(v, 3) for k, v in legs.wall.items()}
+        result["legs_gpu_event_s"] = {k: round(v, 3) for k, v in legs.gpu.items()}
+        result["gpu_event_seconds"] = round(sum(legs.gpu.values()), 3)
+        result["wall_seconds"] = round(time.perf_counter() - t_start, 3)
+        result["legs_note"] = ("wall seconds of rank 0 per leg; legs_gpu_event_s: the span between a HIP event recorded on the launch "
+                               "stream at the start of the leg and one at its end (the GPU side of the same leg, idle gaps while the host "
+                               "builds loops included); gpu_event_seconds their sum.  At n_gpus = 1 the CPU baseline runs first, before "
+                               "the HIP context exists: GPU activity starts after legs_wall_s.cpu_baseline seconds")
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
     return 0

@@ -109,6 +109,7 @@ def run_generation(theta, init_states, episodes, max_step, process_num, fixed_le
 
 def time_baseline(process_num=None, offspring_per_proc=6, episodes=5, max_step=500, seed=0):
     """Bounded sample of the benchmark workload (CartPole, MLP, theta = 0.1*eps, fixed-length episodes)."""
+    t_begin = time.perf_counter()
     process_num = process_num or os.cpu_count() or 1
     n = max(16, offspring_per_proc * process_num)
     rng = np.random.RandomState(seed)
@@ -122,13 +123,31 @@ def time_baseline(process_num=None, offspring_per_proc=6, episodes=5, max_step=5
     t0 = time.perf_counter()
     c_oracle.rollout_cartpole(theta[:64], init, episodes, max_step, mode=c_oracle.MODE_FIXED_LENGTH)
     c_rate = 64 * episodes * max_step / (time.perf_counter() - t0)
-    model = "unknown"
+    model, physical, sockets = "unknown", None, None
     try:
         with open("/proc/cpuinfo") as f:
-            model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+            text = f.read()
+        model = next(line.split(":", 1)[1].strip() for line in text.splitlines() if line.startswith("model name"))
+        # physical cores = distinct (socket, core id) pairs; logical CPUs = processor entries (SMT siblings share a pair)
+        pairs, sock, core = set(), None, None
+        for line in text.splitlines() + [""]:
+            if line.startswith("physical id"):
+                sock = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if sock is not None and core is not None:
+                    pairs.add((sock, core))
+                sock = core = None
+        if pairs:
+            physical, sockets = len(pairs), len({p[0] for p in pairs})
     except (OSError, StopIteration):
         pass
     return {"value": steps / dt, "unit": "env-steps/s", "cores": process_num, "kind": "port",
+            "cores_logical": os.cpu_count(), "cores_physical": physical, "sockets": sockets,
+            "cores_note": "`cores` = worker processes of the pool = logical CPUs the host shows (SMT siblings count twice); "
+                          "cores_physical = distinct (socket, core id) pairs in /proc/cpuinfo",
+            "seconds": time.perf_counter() - t_begin,
             "sample": f"{n} offspring x {episodes} episodes x {max_step} fixed-length steps = {steps} env-steps "
                       f"in {dt:.2f}s, mp.Pool({process_num}), batch-1 torch forward + Python CartPole per step",
             "value_1_process": steps1 / dt1, "c_oracle_1_core": c_rate, "cpu_model": model}

@@ -483,8 +483,11 @@ int ses_allgather_fitness(ses_handle *h, const float *local, int32_t n_per_rank,
     SES_REQUIRE(h && local && all, "ses_allgather_fitness: null argument");
     SES_REQUIRE(n_per_rank >= 1, "ses_allgather_fitness: n_per_rank must be >= 1");
     if (h->p2p && h->p2p->attached && n_per_rank <= h->p2p->max_per_rank / 2 && !(h->tune_comm_force_rccl && h->comm) &&
-        h->tune_comm_granules) {
-        // granules: the data is the flag (k_allgather_granules); shards beyond half a mailbox section take the flag-based kernel
+        h->tune_comm_granules && h->tune_comm_granules_enabled) {
+        // granules: the data is the flag (k_allgather_granules); shards beyond half a mailbox section take the flag-based kernel;
+        // with the granules switched off for this transport (comm_granules_enabled = 0 after a failed self-test) the branch is
+        // not entered at all -- comm_p2p_granules_begin would format an "unsupported" message on every exchange and leave it in
+        // ses_last_error behind a call that succeeds
         SES_HIP_TRY(hipSetDevice(h->cfg.device));
         P2pGranuleView gv;
         const int grc = comm_p2p_granules_begin(h, n_per_rank, &gv);

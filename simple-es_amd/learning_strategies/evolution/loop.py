@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 from ses import HipES, MODE_EPISODIC, MODE_FIXED_LENGTH
-from ses.parallel import all_ranks, attach_comm, comm_failed, comm_keep_going, comm_recover
+from ses.parallel import all_ranks, attach_comm, comm_failed, comm_keep_going, comm_recover, world_size
 
 from .abstracts import BaseESLoop
 
@@ -36,8 +36,7 @@ class _GenerationBatch:
         hooked = any(name in loop.__dict__ or getattr(type(loop), name) is not getattr(ESLoop, name)
                      for name in ("rollout", "generation", "_init_states"))        # a caller observing the per-generation methods
         shard = population.shard
-        dist_world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        if shard.world != dist_world:
+        if shard.world != world_size():
             return False
         if shard.world > 1:
             # sharded run: the C loop all-gathers the fitness itself, so a LIBRARY transport (peer stores or RCCL) has to
@@ -206,7 +205,7 @@ class ESLoop(BaseESLoop):
 
         # logs/<env>/<timestamp>[_k]: the reference's makedirs (loop.py:40-47) raises when two loops start in the same
         # second; here the second one gets a suffix instead of silently sharing the directory.  Only rank 0 writes.
-        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        rank = dist.get_rank() if (world_size() > 1 and dist.is_available() and dist.is_initialized()) else 0
         self.save_dir = None
         if rank == 0:
             stamp = datetime.now().strftime("%Y%m%d%H%M%S")
@@ -501,13 +500,18 @@ class ESLoop(BaseESLoop):
         ses_run_generations when the run is eligible for it (bench.py's timed call on several GPUs), k x generation()
         otherwise.  Returns the next offspring group."""
         strategy = self.offspring_strategy
+        owner = getattr(self.dev, "_comm_owner", None)
+        route = owner.comm_route() if owner is not None else None       # (cached on the handle: no ctypes call)
         batch = getattr(self, "_bench_batch", None)
-        if batch is None or batch[0] is not offsprings:
-            made = self._generation_batch(strategy, offsprings)          # (collective on a sharded run)
-            batch = (offsprings, made) if made is not None else None
-        if batch is None:
+        if batch is None or batch[0] is not offsprings or batch[2] != route:
+            # (collective on a sharded run: an all-reduce + .item(), i.e. a device sync with the nccl backend -- so the answer
+            #  is kept, the negative one too, for as long as the caller hands back the population this method returned and the
+            #  transports are the ones the answer was given for)
+            batch = (offsprings, self._generation_batch(strategy, offsprings), route)
+        if batch[1] is None:
             for _ in range(k):
                 offsprings, _best, _sigma, _stamp = self.generation(offsprings)
+            self._bench_batch = (offsprings, None, route)
             return offsprings
         done = 0
         while done < k:
@@ -515,8 +519,14 @@ class ESLoop(BaseESLoop):
             batch[1].run(step)
             done += step
         pop = batch[1].sync_back()
-        self._bench_batch = (pop, batch[1])
+        self._bench_batch = (pop, batch[1], route)
         return pop
+
+    @property
+    def device_side_loop(self):
+        """True when the last generations() call went through ses_run_generations (bench.py reports it)."""
+        b = getattr(self, "_bench_batch", None)
+        return bool(b is not None and b[1] is not None)
 
 
 class _Ready:

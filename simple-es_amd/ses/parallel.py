@@ -12,6 +12,7 @@ mailboxes inside a node, RCCL otherwise): `attach_comm(dev)` sets the transports
 control plane that carries the mailbox handles / rank 0's 128-byte RCCL id between the ranks.  The torch.distributed
 route further down is what is left when neither is available (CPU tensors, or SES_COMM_P2P=0 with backend "gloo").
 """
+import contextlib
 import os
 import socket
 import sys
@@ -20,8 +21,31 @@ import torch
 import torch.distributed as dist
 
 
+_SOLO = 0      # > 0 inside `with solo():` -- this process then behaves like a single-rank run
+
+
 def _dist_on():
-    return dist.is_available() and dist.is_initialized()
+    return _SOLO == 0 and dist.is_available() and dist.is_initialized()
+
+
+def world_size(group=None):
+    """Ranks the population is sharded over: the process group's size, 1 without one or inside `with solo():`."""
+    return dist.get_world_size(group) if _dist_on() else 1
+
+
+@contextlib.contextmanager
+def solo():
+    """Inside the block this process is a world of ONE, whatever process group exists: Shard() owns every row, attach_comm()
+    is a no-op and ESLoop / the strategies take their single-GPU paths.  For a rank that has to RECOMPUTE on its own what the
+    sharded run produced -- bench.py's `shard_check`, the multi-GPU tests -- without leaving the process group.  Objects built
+    inside the block stay single-rank afterwards (their Shard is fixed at construction); the peers must not be inside a
+    collective that waits for this rank meanwhile."""
+    global _SOLO
+    _SOLO += 1
+    try:
+        yield
+    finally:
+        _SOLO -= 1
 
 
 _COMM = {}   # (group, world) -> HipES handle that owns this process's communicator(s), or False (torch route)

@@ -782,8 +782,96 @@ def g6evo_evolution_loop():
     print("G6evo", {k_: meta[k_] for k_ in ("seed", "best", "pop")}, flush=True)
 
 
+# --------------------------------------------------------------------------- G4t
+def capped_cartpole_returns(n, frac_cap, seed):
+    """Returns of a CartPole population in the regime its training lives in: `frac_cap` of the offspring reached the 500-step
+    TimeLimit in every episode (return exactly 500.0); the others have the mean of five integer episode lengths -- multiples of
+    0.2, which tie among themselves too.  Python floats, formed like loop.py:123-124 forms them (float sum / eval_ep_num)."""
+    rng = np.random.RandomState(seed)
+    capped = rng.rand(n) < frac_cap
+    lens = rng.randint(8, 500, size=(n, 5))
+    return [500.0 if capped[i] else float(lens[i].sum()) / 5 for i in range(n)]
+
+
+def g4t_ties():
+    """What the reference does when returns TIE (offspring_strategies.py:112,234,380: `np.flip(np.argsort(np.array(rewards)))`,
+    numpy's default unstable sort -- here numpy 2.2.6, whose float64 argsort dispatches to an AVX-512 quicksort on this CPU).
+    evaluate() of each strategy is run ONCE on a capped-regime reward vector with its argsort result captured (numpy.argsort is
+    wrapped for the duration of the call), the elites identified by object identity, openai_es's shaped weights read from the
+    frame of evaluate() when it returns (sys.setprofile), and the parent / elite the call produces recorded.  Keys starting with
+    `numpy_` depend on the sort implementation (numpy version AND CPU dispatch); everything else is tie-invariant."""
+    import learning_strategies.evolution.offspring_strategies as ref_mod
+    out, meta = {}, {"numpy": np.__version__, "cases": {}}
+    import numpy._core._multiarray_umath as _mu                     # which SIMD sort kernels this numpy dispatches to on this CPU
+    meta["cpu_dispatch_avx512"] = sorted(k for k, v in getattr(_mu, "__cpu_features__", {}).items() if v and k.startswith("AVX512"))
+    cases = [
+        ("evo_97", lambda: simple_evolution(2, 0.9999, 10, 96), 97, 10),          # conf/cartpole.yaml
+        ("gen_120", lambda: simple_genetic(2, 0.999, 10, 120), 120, 10),          # conf/bipedalwalker.yaml's strategy block
+        ("es_256", lambda: openai_es(0.1, 0.999, 0.05, 256), 256, 0),
+        ("es_4096", lambda: openai_es(0.1, 0.999, 0.05, 4096), 4096, 0),          # the headline population
+    ]
+    for name, make, n, k in cases:
+        for frac in ((0.6,) if name == "es_4096" else (0.3, 0.6, 0.9)):
+            tag = f"{name}_cap{int(frac * 100)}"
+            seed = 40 + int(frac * 10)
+            set_seed(seed)
+            strat = make()
+            net = GymEnvModel(4, 2, True, False)
+            net.zero_init()
+            pop = strat.init_offspring(net, ["0"])
+            assert len(pop) == n
+            rewards = capped_cartpole_returns(n, frac, 1000 + seed)
+            before = list(strat.offsprings) if hasattr(strat, "offsprings") and strat.offsprings else None
+            mu_before = flat(strat.mu_model) if hasattr(strat, "mu_model") else None
+            captured, weights = [], []
+            real_argsort = np.argsort
+
+            def spy(a, *args, **kw):
+                r = real_argsort(a, *args, **kw)
+                captured.append(np.array(r))
+                return r
+
+            def prof(frame, event, arg):
+                if event == "return" and frame.f_code.co_name == "evaluate" and "reward_array" in frame.f_locals:
+                    weights.append(np.array(frame.f_locals["reward_array"], dtype=np.float64))
+
+            np.argsort = spy
+            sys.setprofile(prof)
+            try:
+                _, best, sigma = strat.evaluate(rewards)
+            finally:
+                sys.setprofile(None)
+                np.argsort = real_argsort
+            assert len(captured) == 1 and captured[0].shape == (n,)
+            order = np.flip(captured[0])                                # what evaluate() ranked by
+            out[f"{tag}_rewards"] = np.array(rewards)
+            out[f"{tag}_numpy_order"] = order.astype(np.int32)
+            info = {"n": n, "elite_num": k, "frac_cap": frac, "seed": seed, "best": float(best), "sigma": float(sigma),
+                    "at_cap": int(sum(r == 500.0 for r in rewards)), "distinct": len(set(rewards))}
+            if k:
+                # the elites evaluate() kept ARE the population members the captured order names (object identity; slots that
+                # hold the same module object -- simple_evolution's slots 0 and 1 -- are told apart by the order alone)
+                ids = [int(i) for i in order[:k]]
+                assert all(before[i] is em for i, em in zip(ids, strat.elite_models))
+                out[f"{tag}_numpy_elite_ids"] = np.array(ids, dtype=np.int32)
+                out[f"{tag}_numpy_elite"] = flat(strat.get_elite_model())
+                out[f"{tag}_theta0"] = pop_matrix(pop)
+            else:
+                assert len(weights) == 1
+                out[f"{tag}_numpy_weights"] = weights[0]
+                out[f"{tag}_numpy_mu"] = flat(strat.mu_model)
+                out[f"{tag}_mu_before"] = mu_before
+            meta["cases"][tag] = info
+            print("G4t", tag, info, flush=True)
+    np.savez_compressed(os.path.join(OUT, "g4t_ties.npz"), **out)
+    with open(os.path.join(OUT, "g4t_ties.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g234", "g56", "g6es", "g6gen", "g6evo", "g7", "g7t", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g234", "g4t", "g56", "g6es", "g6gen", "g6evo", "g7", "g7t", "g8", "g9", "g10"]
+    if "g4t" in which:
+        g4t_ties()
     if "g6es" in which:
         g6es_openai_loop()
     if "g6gen" in which:

@@ -170,3 +170,106 @@ def test_two_gpus_equal_one_gpu_bitwise(tmp_path, p2p):
             assert np.array_equal(got["fits"].view(np.uint32), ref["fits"].view(np.uint32)), (name, r, "fitness")
             assert np.array_equal(got["elite"].view(np.uint32), ref["elite"].view(np.uint32)), (name, r, "elite")
             assert np.array_equal(got["best"], ref["best"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Real devices, worlds of 2 / 4 / 8, the three population shapes bench.py times at N GPUs.  These tests only
+# wake up on a multi-GPU node (the pool's boxes have one GPU and a guard of six GPU processes): there they are the first thing that
+# says whether the replacement of `Pool.map` (loop.py:66-79) returns every result, in order, on real xGMI links -- on both transports.
+SCALE_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np, torch
+    sys.path[:0] = [%r, %r]
+    out_dir, per_rank_list, world_run = sys.argv[1], [int(x) for x in sys.argv[2].split(",")], int(sys.argv[3])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    rig = os.environ.get("SES_TEST_BACKEND", "nccl") == "gloo"        # the ranks share GPU 0 (1-GPU boxes): gloo control plane
+    if world > 1:
+        import torch.distributed as dist
+        local = 0 if rig else int(os.environ["LOCAL_RANK"])
+        torch.cuda.set_device(local)
+        if rig:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import builder
+    from ses.parallel import comm_info, comm_transport
+    os.chdir(out_dir)
+    for per in per_rank_list:
+        n = per * world_run                     # the single-rank reference run computes the population of the `world_run`-rank job
+        cfg = {"env": {"name": "CartPole-v1", "max_step": 60, "pomdp": False, "seed": 11, "shared_init": True, "fixed_length": True},
+               "network": {"name": "gym_model", "num_state": 4, "num_action": 2, "discrete_action": True, "gru": False},
+               "strategy": {"name": "openai_es", "init_sigma": 0.4, "sigma_decay": 0.995, "learning_rate": 0.05,
+                            "offspring_num": n, "seed": 2}}
+        loop = builder.build_loop(cfg, 0, 1, 5, False, 10 ** 9)
+        strat = loop.offspring_strategy
+        pop = strat.init_offspring(loop.network, loop.env.get_agent_ids())
+        if world > 1:
+            want = "rccl" if os.environ.get("SES_COMM_P2P") == "0" else "p2p-store"
+            assert rig or comm_info(loop.dev)[1] == world, comm_info(loop.dev)    # an RCCL communicator over ALL the ranks
+            assert comm_transport(loop.dev, pop.shard.per_rank) == want, comm_transport(loop.dev, pop.shard.per_rank)
+        # (1) the per-generation calls: every rank's all-gathered fitness vector, two generations
+        fits = []
+        for g in range(2):
+            fit = loop.rollout(pop)
+            fits.append(fit.cpu().numpy().copy())
+            pop, best, sigma = strat.evaluate(fit)
+        # (2) the call bench.py times: four generations through ESLoop.generations (on a library transport the device-side loop,
+        # both exchanges inside the kernels around them)
+        pop = loop.generations(pop, 4)
+        torch.cuda.synchronize()
+        sh = pop.shard
+        np.savez(os.path.join(out_dir, f"n{n}_w{world}_r{rank}.npz"), fits=np.stack(fits), mu=strat.mu_model.cpu().numpy(),
+                 m=strat.optimizer.m.cpu().numpy(), v=strat.optimizer.v.cpu().numpy(), theta=pop.theta.cpu().numpy(),
+                 first=np.array(sh.first), n_local=np.array(sh.n_local), device_loop=np.array(bool(loop.device_side_loop)))
+        del loop, strat, pop
+    if world > 1:
+        dist.destroy_process_group()
+""")
+
+
+def _bench_shapes_many_against_one(tmp_path, world, p2p, rig):
+    script = tmp_path / "scale.py"
+    script.write_text(SCALE_WORKER % (ROOT, SRC))
+    pers = [4096 // world, 4096, 8192]
+    arg = ",".join(str(p) for p in pers)
+    one = subprocess.run([sys.executable, str(script), str(tmp_path), arg, str(world)], capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), str(tmp_path), arg, str(world)],
+                          capture_output=True, text=True, timeout=900,
+                          env={**os.environ, "SES_COMM_P2P": p2p, "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                               "SES_TEST_BACKEND": "gloo" if rig else "nccl"})
+    assert many.returncode == 0, many.stdout[-2000:] + many.stderr[-4000:]
+    for per in pers:
+        n = per * world
+        ref = np.load(tmp_path / f"n{n}_w1_r0.npz")
+        assert ref["fits"].std() > 0 and np.abs(ref["mu"]).sum() > 0
+        for r in range(world):
+            got = np.load(tmp_path / f"n{n}_w{world}_r{r}.npz")
+            for key in ("fits", "mu", "m", "v"):
+                assert np.array_equal(got[key].view(np.uint32), ref[key].view(np.uint32)), (n, r, key)
+            lo, k = int(got["first"]), int(got["n_local"])
+            assert (lo, k) == (r * per, per)
+            assert np.array_equal(got["theta"].view(np.uint32), ref["theta"][lo:lo + k].view(np.uint32)), (n, r, "next population")
+            assert bool(got["device_loop"]), "a library transport carries the shards: the timed path is the device-side loop"
+
+
+@pytest.mark.parametrize("p2p", ["1", "0"], ids=["peer_stores_over_xgmi", "rccl"])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_real_gpus_equal_one_gpu_bitwise_at_the_bench_shapes(tmp_path, world, p2p):
+    """world GPUs against one, bit for bit, at the three jobs bench.py times on `world` GPUs: the strong job of record (4096
+    offspring in total: 8 x 512), the weak job (4096 per GPU) and C4's layout (8192 per GPU: 8 x 8192 = 65 536)."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs (RCCL refuses two ranks on one device), this box shows {torch.cuda.device_count()}")
+    _bench_shapes_many_against_one(tmp_path, world, p2p, rig=False)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_the_bench_shapes_on_the_rig_whose_ranks_share_the_gpu(tmp_path, world):
+    """The same worker and the same comparisons with the ranks SHARING this box's GPU (gloo control plane, peer stores through
+    hipIpc): what a 1-GPU box can say about the test above -- that the test itself is sound -- before a node runs it."""
+    _bench_shapes_many_against_one(tmp_path, world, "1", rig=True)

@@ -94,6 +94,20 @@ AGREE_WORKER = textwrap.dedent("""
     if rank == 0:                      # called on ONE rank only: must return at once
         assert attach_comm(h, create=False) is False and h._comm_owner is None
     dist.barrier()
+    # solo(): ONE rank steps out of the world to recompute what the sharded run produced (bench.py's shard_check): inside the
+    # block it owns every row, collective helpers answer locally, attach_comm is a no-op; outside nothing has changed
+    from ses.parallel import Shard, solo, world_size
+    if rank == 0:
+        with solo():
+            sh = Shard(4096)
+            assert (sh.world, sh.rank, sh.first, sh.n_local) == (1, 0, 0, 4096) and world_size() == 1
+            assert all_ranks(False, dev) is False and all_ranks(True, dev) is True      # no collective: rank 1 is not here
+            assert attach_comm(h) is False
+            x = torch.arange(5.0)
+            assert sh.allgather_fitness(x) is x
+    sh = Shard(4096)
+    assert (sh.world, sh.rank, sh.first, sh.n_local) == (2, rank, 2048 * rank, 2048) and world_size() == 2
+    dist.barrier()
     open(sys.argv[1] + "/agree" + str(rank) + ".ok", "w").write("ok")
     dist.destroy_process_group()
 """)

@@ -33,5 +33,5 @@ if rank == 0:
     print(json.dumps({"ranks_on_one_gpu": world, "rows_per_rank": per, "tuning": os.environ.get("SES_TUNING", ""),
                       "us_per_generation": round(statistics.median(ts), 2), "min": round(min(ts), 2),
                       "exchanges_flag_granule": owner.comm_p2p_counts() if owner else None,
-                      "device_loop": bool(loop.batched_generations or getattr(loop, "_bench_batch", None))}), flush=True)
+                      "device_loop": bool(loop.batched_generations or loop.device_side_loop)}), flush=True)
 dist.destroy_process_group()
