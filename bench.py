@@ -440,10 +440,24 @@ def shard_check(job, args, world, rank, dist, backend, gens=4):
     t0 = time.perf_counter()
     out = {"generations": gens, "offspring_total": n, "ranks": world,
            "timed_path": "device-side loop (ses_run_generations)" if loop.device_side_loop else "per-generation calls"}
+    # from a YOUNG population: after the thousands of generations of the timed blocks every offspring sits at the 500-step cap and a
+    # fitness vector of 4096 x 500.0 would compare equal whatever the exchange did with it.  Three generations from the zero
+    # network the returns are spread over dozens of values (fitness_distinct_values below; checked)
+    job.reset()
+    job.generations(3)
     pop = job.pop
     snap = strat.snapshot(pop)
     # ---- fitness -------------------------------------------------------------------------------------------------
-    fit_all = loop.rollout(pop).clone()
+    if os.environ.get("SES_BENCH_FAULT") == "shard" and rank == world - 1:
+        # TEST HOOK (tests/test_gpu_multirank.py::test_bench_shard_check_catches_a_wrong_shard): the last rank corrupts one value
+        # of its shard before the exchange -- the certification must say so on every rank
+        shard = pop.shard
+        init = loop._init_states(pop.gen, shard)
+        local = dev.rollout(pop.theta, init, mode=loop.mode)
+        local[shard.n_local // 2] += 1.0
+        fit_all = shard.allgather_fitness(local, dev=dev).clone()
+    else:
+        fit_all = loop.rollout(pop).clone()
     fit_one = torch.empty_like(fit_all)
     if rank == 0:
         last = strat._last
@@ -480,6 +494,7 @@ def shard_check(job, args, world, rank, dist, backend, gens=4):
     same_state = bool(torch.equal(mine.view(torch.int32), ref.view(torch.int32)))
     out["state_mismatches_this_rank"] = int((mine.view(torch.int32) != ref.view(torch.int32)).sum().item())
     out["state_nonzero"] = bool(ref.abs().sum().item() > 0)
+    same_fit = same_fit and out["fitness_distinct_values"] >= 8            # a constant vector certifies nothing
     out["fitness_bit_equal"] = parallel.all_ranks(same_fit, dev.device)
     out["state_bit_equal"] = parallel.all_ranks(same_state, dev.device)
     out["bit_equal"] = bool(out["fitness_bit_equal"] and out["state_bit_equal"])
@@ -490,11 +505,11 @@ def shard_check(job, args, world, rank, dist, backend, gens=4):
     return out
 
 
-def rank0_legs(args, result, legs, job, es, world, E, T, skip):
+def rank0_legs(args, result, timer, job, es, world, E, T, skip):
     """The legs only rank 0 runs (at n_gpus > 1 the peers wait at the final barrier meanwhile): per-kernel view of the headline
     generation, BASELINE configs[2], the Box2D MLP configs, the env-step roofline, the one-rank RCCL round trip."""
     # per-kernel view of one generation (rank 0, HIP events on the launch stream)
-    legs.begin("rollout_kernel")
+    timer.begin("rollout_kernel")
     pop = job.pop
     init = es.init_states_uniform(0, 0, 0, 1, shared=True)[0]
     samples = []
@@ -588,11 +603,11 @@ def rank0_legs(args, result, legs, job, es, world, E, T, skip):
             else:
                 result["rollout_kernel"]["valu_issue_model_note"] = (f"profiles/{models[-1]} prices different machine code of this "
                                                                      "kernel (rerun tools/issue_model.py): not attached")
-    legs.end()
+    timer.end()
     # BASELINE.json configs[2]: LunarLanderContinuous-v2 POMDP, GRU policy, 4096 offspring (conf/lunarlander_openai.yaml):
     # one rollout of first-generation policies (sigma = init_sigma around the zero network), episodic
     if not args.no_extras and not args.gru and "c3" not in skip:
-        legs.begin("c3_lunarlander")
+        timer.begin("c3_lunarlander")
         try:
             from ses import HipES
             c3 = HipES("LunarLanderContinuous-v2", 8, 4, False, True, pomdp=True, max_step=300, eval_ep_num=5)
@@ -667,11 +682,11 @@ def rank0_legs(args, result, legs, job, es, world, E, T, skip):
             c3.close()
         except Exception as exc:
             result["c3_error"] = repr(exc)
-        legs.end()
+        timer.end()
     # conf/bipedalwalker.yaml and conf/lunarlander.yaml at 4096 offspring x 5 episodes x <= 300 steps (MLP policies on the
     # Box2D-style world, continuous collision on): one warm rollout, the median of two
     if not args.no_extras and not args.gru and world == 1 and "box2d" not in skip:
-        legs.begin("box2d_mlp")
+        timer.begin("box2d_mlp")
         try:
             from ses import HipES
             legs = {}
@@ -700,17 +715,17 @@ def rank0_legs(args, result, legs, job, es, world, E, T, skip):
             result["box2d_mlp_4096"] = legs
         except Exception as exc:
             result["box2d_mlp_error"] = repr(exc)
-        legs.end()
+        timer.end()
     if not args.no_roofline:
-        legs.begin("roofline")
+        timer.begin("roofline")
         try:
             result["roofline"] = env_step_roofline(es, args.roofline_envs)
             attach_traffic(result["roofline"], args.roofline_envs)
         except Exception as exc:                                   # the headline line must still be printed
             result["roofline_error"] = repr(exc)
-        legs.end()
+        timer.end()
     if world == 1:
-        legs.begin("rccl_single_rank")
+        timer.begin("rccl_single_rank")
         # the RCCL path of the library on this box: a one-rank communicator (ncclAllGather of one shard = a copy)
         try:
             from ses import HipES
@@ -731,7 +746,7 @@ def rank0_legs(args, result, legs, job, es, world, E, T, skip):
             solo.close()
         except Exception as exc:
             result["rccl_single_rank"] = {"error": repr(exc)}
-        legs.end()
+        timer.end()
 
 
 def run_rank(args):

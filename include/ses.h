@@ -74,7 +74,7 @@ typedef struct ses_config {
     int32_t max_step;        /* env.max_step (gym_wrapper.py:37-39); CartPole-v1 TimeLimit = 500 */
     int32_t eval_ep_num;     /* --eval-ep-num, run_es.py:33-38                                   */
     int32_t device;          /* HIP device ordinal                                               */
-    int32_t lanes_per_env;   /* 0 = choose from the population size; else 1, 2, 4, 8 or 16       */
+    int32_t lanes_per_env;   /* 0 = choose from the population size; else 1, 2, 4, 8, 16 or 32   */
     int32_t n_agents;        /* simple_spread: agents (= landmarks) per env, 2 (reference) or 3; else 1 */
     int32_t physics64;       /* CartPole rollouts only: 1 = gym-order float64 dynamics (csrc/ses_cartpole.h),   */
                              /* 0 = folded-constant fp32 (default, benchmark path)                              */
@@ -89,7 +89,7 @@ int ses_sync(ses_handle *h);
 /* Development / test hook: which of the (result-identical) rollout kernels a handle picks.  Every kernel evaluates the
  * same canonical arithmetic, so no setting changes a result; the defaults are the measured crossovers.  Knobs:
  * "gru_ep_parallel_max" (default 4096), "gru_mfma_min_e" (12), "gru_sequential" (0), "rollout_mix" (1),
- * "rollout_waves8" (1024: light waves of the mixed CartPole MLP split), "rollout_mix_light" (their lanes per env: 0 = choose | 8 | 16), "rollout_block" (64 | 256), "lander_offspring_per_wave" (0 = by population size | 1 | 2 | 4),
+ * "rollout_waves8" (1024: light waves of the mixed CartPole MLP split), "rollout_mix_light" (their lanes per env: 0 = choose | 8 | 16), "rollout_lpe32_max_envs" (0: CartPole MLP populations of up to this many envs run at 32 lanes per env), "rollout_block" (64 | 256), "lander_offspring_per_wave" (0 = by population size | 1 | 2 | 4),
  * "box2d_lanes_per_env" (0 = by population size | 1 | 2 | ... | 64: lanes that share one env in the LunarLander / BipedalWalker MLP rollout),
  * "box2d_envs_per_wave" (0 = by population size | 1 ... 64 / lanes per env: different envs a wave of that rollout carries),
  * "env_step_block" (64 | 128 | 256), "env_step_waves_per_cu" (1 ... 32, default 7) and "env_step_lds_bytes" (-1 ... 65536,

@@ -84,8 +84,8 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     SES_REQUIRE(cfg->eval_ep_num >= 1, "ses_create: eval_ep_num must be >= 1");
     SES_REQUIRE(cfg->max_step >= 1 && cfg->max_step < (1 << 30), "ses_create: max_step must be in [1, 2^30)");
     SES_REQUIRE(cfg->lanes_per_env == 0 || cfg->lanes_per_env == 1 || cfg->lanes_per_env == 2 ||
-                    cfg->lanes_per_env == 4 || cfg->lanes_per_env == 8 || cfg->lanes_per_env == 16,
-                "ses_create: lanes_per_env must be 0, 1, 2, 4, 8 or 16");
+                    cfg->lanes_per_env == 4 || cfg->lanes_per_env == 8 || cfg->lanes_per_env == 16 || cfg->lanes_per_env == 32,
+                "ses_create: lanes_per_env must be 0, 1, 2, 4, 8, 16 or 32");
     if (cfg->env_id == SES_ENV_CARTPOLE)
         SES_REQUIRE(cfg->num_state == 4 && cfg->num_action == 2 && cfg->discrete_action,
                     "ses_create: CartPole needs num_state=4 num_action=2 discrete_action=1");
@@ -164,6 +164,7 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"rollout_mix", &ses_handle::tune_rollout_mix, 0, 1},
                                  {"rollout_waves8", &ses_handle::tune_rollout_waves8, 1, 1 << 20},
                                  {"rollout_mix_light", &ses_handle::tune_rollout_mix_light, 0, 16},
+                                 {"rollout_lpe32_max_envs", &ses_handle::tune_rollout_lpe32_max, 0, 1 << 30},
                                  {"lander_offspring_per_wave", &ses_handle::tune_lander_per_wave, 0, 4},
                                  {"box2d_lanes_per_env", &ses_handle::tune_box2d_lpe, 0, 64},
                                  {"box2d_envs_per_wave", &ses_handle::tune_box2d_epw, 0, 64},

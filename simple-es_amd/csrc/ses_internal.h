@@ -34,6 +34,7 @@ struct ses_handle {
     int tune_rollout_mix;          // 0: no mixed LPE-8 / LPE-4 split for mid-sized CartPole MLP populations
     int tune_rollout_waves8;       // light waves of the mixed split
     int tune_rollout_mix_light;    // lanes per env of the light waves: 0 = choose, 8, 16
+    int tune_rollout_lpe32_max;    // CartPole MLP populations of up to this many envs run at 32 lanes per env (0: never)
     // ses_set_stamp: where the next stamped launch of this handle writes the GPU real-time counter (or null)
     unsigned long long *stamp;
     // ses_openai_generation: the rank vector in red_scratch that is known to be zero (left so by the update kernel)

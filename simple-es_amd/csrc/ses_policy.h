@@ -37,6 +37,12 @@ constexpr int DPP_ROW_ROR8 = 0x128;        // lane i <- lane (i + 8) % 16 inside
 constexpr int DPP_ROW_ROR12 = 0x12C;       // row_ror:12: lane i <- lane (i + 4) % 16
 constexpr int DPP_QUAD_00_22 = 0xA0;       // quad_perm [0,0,2,2]: odd lanes <- their even neighbour
 constexpr int DPP_ROW_BCAST1 = 0x151;      // row_newbcast:1: every lane of a row <- lane 1 of the row
+constexpr int DPP_ROW_NEWBCAST15 = 0x15F;    // row_newbcast:15: every lane of a row <- lane 15 of the row
+constexpr int DPP_ROW_ROR4 = 0x124;        // row_ror:4: lane i <- lane (i + 12) % 16 = i - 4
+constexpr int DPP_QUAD_BCAST0 = 0x00;      // quad_perm [0,0,0,0]: every lane of a quad <- its lane 0
+constexpr int DPP_QUAD_BCAST1 = 0x55;      // quad_perm [1,1,1,1]
+constexpr int DPP_QUAD_BCAST2 = 0xAA;      // quad_perm [2,2,2,2]
+constexpr int DPP_QUAD_BCAST3 = 0xFF;      // quad_perm [3,3,3,3]
 
 // sum over the LPE lanes that share one env; every lane ends with the same bits
 template <int LPE>
@@ -56,10 +62,16 @@ struct MlpSlice {
     // one through one DPP move, the tree over the 8 groups runs over the odd lanes of the row, and the action is
     // broadcast to the row (finish() below).  Same canonical arithmetic, 83 instead of 104 (LPE 8) VALU instructions
     // per step and wave: for populations that cannot fill the chip otherwise, and as the light wave of the mixed split.
-    static_assert(U % 4 == 0 || U == 2, "a lane owns whole fc2 groups, or a lane pair owns one");
+    // LPE = 32 (U = 1, round 6): a lane QUAD owns one fc2 group.  Every lane of the quad keeps the group's four W2 columns and
+    // fetches the three activations it does not own through the DPP operand of the multiply / fma itself (quad broadcasts:
+    // no separate move), so all four lanes hold the group's in-order chain; the tree over the 8 groups -- one per quad, four
+    // per 16-lane row -- runs inside the rows (row_ror 4, 8) and crosses the two rows of the env with one
+    // v_permlane16_swap on two copies.  For populations of at most 2048 envs (<= 1024 waves at two envs per wave).
+    static_assert(U % 4 == 0 || U == 2 || U == 1, "a lane owns whole fc2 groups, or a lane pair / quad owns one");
+    static constexpr int W2N = U <= 2 ? 4 : U;      // W2 columns a lane keeps per output
     float w1[U][S];   // times 32 (the tanh table's 1/h), see tanh_index_scaled
     float b1[U];      // times 32
-    float w2[A][U];
+    float w2[A][W2N];
     float b2[A];
 
     // theta: this offspring's row; sub: lane index inside the env's lane group
@@ -78,8 +90,21 @@ struct MlpSlice {
         }
 #pragma unroll
         for (int a = 0; a < A; ++a) {
+            if constexpr (U == 1) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) w2[a][u] = pw2[a * H + j0 + u];
+                for (int u = 0; u < 4; ++u) w2[a][u] = pw2[a * H + (j0 & ~3) + u];       // the whole group of this lane's quad
+            } else if constexpr (U == 2) {
+                // own columns first, then the columns of the pair's EVEN lane (what an odd lane multiplies its neighbour's
+                // activations with; an even lane reads its own again, nobody uses its result)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    w2[a][u] = pw2[a * H + j0 + u];
+                    w2[a][2 + u] = pw2[a * H + (j0 & ~3) + u];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) w2[a][u] = pw2[a * H + j0 + u];
+            }
             b2[a] = pb2[a];
         }
     }
@@ -124,12 +149,35 @@ struct MlpSlice {
         float a[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) a[u] = tanh_eval(pd.ent[u], pd.frac[u], pd.pre[u]);
+        if constexpr (U == 1) {
+#pragma unroll
+            for (int o = 0; o < A; ++o) {
+                // the group's canonical chain in every lane of the quad: a[4g + k] arrives through the DPP operand
+                // (hipcc folds the move into the v_mul_f32_dpp / v_fmac_f32_dpp that uses it: no instruction of its own)
+                float q = dpp_mov<DPP_QUAD_BCAST0>(a[0]) * w2[o][0];
+                q = fma_(dpp_mov<DPP_QUAD_BCAST1>(a[0]), w2[o][1], q);
+                q = fma_(dpp_mov<DPP_QUAD_BCAST2>(a[0]), w2[o][2], q);
+                q = fma_(dpp_mov<DPP_QUAD_BCAST3>(a[0]), w2[o][3], q);
+                // tree: quads of a row hold p0..p3 (row 0 of the env) / p4..p7 (row 1); commutativity of the IEEE add makes
+                // (p[i+1] + p[i]) the bits of (p[i] + p[i+1])
+                q = q + dpp_mov<DPP_ROW_ROR4>(q);                  // lanes 4-7: p1 + p0, lanes 12-15: p3 + p2
+                q = q + dpp_mov<DPP_ROW_ROR8>(q);                  // lanes 12-15: (p3 + p2) + (p1 + p0)
+                float lo = q, hi = q;
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+                q = lo + hi;                                       // lanes 12-15 of both rows: (p0..p3) + (p4..p7)
+                logits[o] = dpp_mov<DPP_ROW_NEWBCAST15>(q + b2[o]);
+            }
+            return;
+        }
         if constexpr (U == 2) {
 #pragma unroll
             for (int o = 0; o < A; ++o) {
-                float p = w2[o][0] * a[0];                         // even lane: units 4g, 4g + 1 of the group's chain
-                p = fma_(w2[o][1], a[1], p);
-                float q = dpp_mov<DPP_QUAD_00_22>(p);              // odd lane <- the chain so far
+                // the ODD lane of a pair evaluates the group's whole in-order chain: units 4g, 4g + 1 live in its even
+                // neighbour and arrive through the DPP operand of the multiply / fma (round 6: four instructions and four
+                // dependent steps, where the even lane's partial chain + a move + the odd lane's half took five); w2[o][2..3]
+                // are the even lane's columns.  (Even lanes compute something nobody reads.)
+                float q = dpp_mov<DPP_QUAD_00_22>(a[0]) * w2[o][2];
+                q = fma_(dpp_mov<DPP_QUAD_00_22>(a[1]), w2[o][3], q);
                 q = fma_(w2[o][0], a[0], q);                       // odd lane: units 4g + 2, 4g + 3
                 q = fma_(w2[o][1], a[1], q);
                 // balanced tree over the 8 group sums, which live in the odd lanes 1, 3, ..., 15 of the row: lanes 1 and 3

@@ -1208,6 +1208,9 @@ struct MlpSplit {
 static MlpSplit choose_cartpole_mlp_split(const ses_handle *h, long long episodes)
 {
     if (h->cfg.lanes_per_env) return MlpSplit{0, h->cfg.lanes_per_env};
+    // round 6: 32 lanes per env (77 VALU instructions per step against 83 at 16, but two more dependent steps in fc2) -- a knob,
+    // off by default: profiles/r06_small_populations.txt has the A/B that decides it
+    if (h->tune_rollout_lpe32_max > 0 && episodes <= h->tune_rollout_lpe32_max) return MlpSplit{0, 32};
     if (episodes > 49152) return MlpSplit{0, 4};                       // large populations: 4 lanes per env (tools/sweep_lpe.sh)
     const int simds = h->tune_rollout_waves8;                           // 1024 = 256 CUs x 4 (knob: the light waves of a mix)
     auto instr = [](int lpe) { return lpe == 4 ? 160.0 : (lpe == 8 ? 104.0 : 84.0); };
@@ -1263,6 +1266,7 @@ static void launch_cartpole_mlp(const ses_handle *h, const float *theta, const f
         case 2: launch_rollout<2>(h, theta, init, per, n_rows, mode, epr, ep_steps); break;
         case 4: launch_rollout<4>(h, theta, init, per, n_rows, mode, epr, ep_steps); break;
         case 16: launch_rollout<16>(h, theta, init, per, n_rows, mode, epr, ep_steps); break;
+        case 32: launch_rollout<32>(h, theta, init, per, n_rows, mode, epr, ep_steps); break;
         default: launch_rollout<8>(h, theta, init, per, n_rows, mode, epr, ep_steps); break;
     }
 }

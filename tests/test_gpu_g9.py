@@ -35,7 +35,7 @@ def g9(golden_dir):
     return np.load(os.path.join(golden_dir, "g9_long.npz"))
 
 
-@pytest.mark.parametrize("lpe", [0, 1, 4, 16])
+@pytest.mark.parametrize("lpe", [0, 1, 4, 16, 32])
 def test_g9_cartpole_mlp(g9, lpe):
     from ses import HipES
     theta, init = g9["mlp_theta"], g9["init_states"]

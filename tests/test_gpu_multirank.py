@@ -494,3 +494,43 @@ def test_run_es_command_line_on_two_ranks(tmp_path):
         saved = sorted(p.name for p in work.glob("logs/*/*/saved_models/*.pt"))
         assert saved == ["ep_10.pt", "ep_5.pt"], saved
     assert outs[1] == outs[2]
+
+
+def _bench_line(world, extra_env, tmp_path, flags=()):
+    import json
+    env = {**os.environ, "SES_BENCH_BACKEND": "gloo", "SES_BENCH_SKIP": "c3 loop e1", **extra_env}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "5", "--warmup", "2",
+                          "--blocks", "2", "--min-timed-seconds", "0", "--preroll", "10", "--no-roofline", *flags],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                     # stdout carries ONE line, the JSON
+    return json.loads(lines[0])
+
+
+def test_bench_multi_gpu_line_certifies_itself(tmp_path):
+    """bench.py --gpus 2 on the rig (ranks share the GPU, gloo control plane): every job of the N > 1 line carries a shard_check --
+    one generation's all-gathered fitness against rank 0's own rollout of the whole population, parent + Adam moments after four
+    generations of the timed call against rank 0's single-rank replay -- and it says bit_equal on a population whose returns
+    are not all the same value; the strong job is the metric as written (4096 offspring in total)."""
+    line = _bench_line(2, {}, tmp_path)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["offspring_total"] == 4096
+    for key, total in (("strong_4096_total", 4096), ("weak_4096_per_gpu", 8192), ("c4_65536_total", 65536)):
+        chk = line[key]["shard_check"]
+        assert chk["offspring_total"] == total and chk["ranks"] == 2, (key, chk)
+        assert chk["bit_equal"] is True and chk["fitness_bit_equal"] is True and chk["state_bit_equal"] is True, (key, chk)
+        assert chk["fitness_distinct_values"] >= 8 and chk["state_nonzero"] is True, (key, chk)
+        assert chk["timed_path"].startswith("device-side loop"), (key, chk)
+        assert line[key + "_rccl"] == "absent"                        # no RCCL communicator spans ranks that share a device
+    assert set(line["legs_wall_s"]) >= {"headline", "headline_shard_check", "weak_4096_per_gpu", "c4_65536_total"}
+    assert line["gpu_event_seconds"] > 0 and line["wall_seconds"] >= line["gpu_event_seconds"] * 0.5
+
+
+def test_bench_shard_check_catches_a_wrong_shard(tmp_path):
+    """The certification is only worth something if it can fail: SES_BENCH_FAULT=shard makes rank 1 perturb ONE fitness value of
+    its shard (bench.py, test hook) before the exchange of the checked generation -- every rank must then report
+    fitness_bit_equal false."""
+    line = _bench_line(2, {"SES_BENCH_FAULT": "shard", "SES_BENCH_SKIP": "c3 loop e1 weak_4096_per_gpu c4_65536_total"}, tmp_path)
+    chk = line["strong_4096_total"]["shard_check"]
+    assert chk["fitness_bit_equal"] is False and chk["bit_equal"] is False, chk
+    assert chk["state_bit_equal"] is True, chk                        # the fault touched the checked exchange only

@@ -286,7 +286,7 @@ def test_env_step_unaligned_views_take_scalar_path(es):
 
 
 # ----------------------------------------------------------------------------------------- rollout
-@pytest.mark.parametrize("lpe", [0, 1, 2, 4, 8, 16])
+@pytest.mark.parametrize("lpe", [0, 1, 2, 4, 8, 16, 32])
 def test_rollout_golden_g5_and_oracle(golden_dir, lpe):
     """Fixture G5: returns of the REFERENCE RolloutWorker + GymEnvModel (torch) over the build's fp32
     CartPole.  Device returns must be within 1e-4 of them and bit-equal to the C oracle, for every
@@ -322,7 +322,7 @@ def test_rollout_per_offspring_init_and_pomdp(es):
     hp.close()
 
 
-@pytest.mark.parametrize("lpe", [0, 4, 8, 16])
+@pytest.mark.parametrize("lpe", [0, 4, 8, 16, 32])
 def test_rollout_wild_initial_states_take_the_general_loop(lpe):
     """Initial pole angles outside |th| <= 0.78 (not a reset the env produces, but the ABI accepts any state):
     such waves run the loop with the full sin/cos argument reduction; waves of ordinary resets run the

@@ -204,7 +204,7 @@ def main():
         sigma = float(rng.choice([0.05, 0.3, 1.0, 3.0]))
         if kind == "mlp":
             n, E, T = int(rng.choice([1, 3, 17, 64, 129, 700, 1700, 2100])), int(rng.randint(1, 8)), int(rng.choice([1, 7, 60, 200]))
-            pomdp, lpe, p64 = bool(rng.randint(0, 2)), int(rng.choice([0, 0, 1, 2, 4, 8, 16])), bool(rng.rand() < 0.15)
+            pomdp, lpe, p64 = bool(rng.randint(0, 2)), int(rng.choice([0, 0, 1, 2, 4, 8, 16, 32])), bool(rng.rand() < 0.15)
             es = HipES("CartPole-v1", 4, 2, True, False, pomdp=pomdp, max_step=T, eval_ep_num=E, lanes_per_env=lpe, physics64=p64)
             theta = (rng.randn(n, 226) * sigma).astype(np.float32)
             init = rng.uniform(-0.05, 0.05, (E, 4) if shared else (n, E, 4)).astype(np.float32)

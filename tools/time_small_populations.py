@@ -5,9 +5,9 @@ import os, sys, json, statistics, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "simple-es_amd")]
 from ses import HipES, MODE_FIXED_LENGTH
-for n in (512, 1024, 2048, 4096):
+for n in (256, 512, 1024, 2048, 4096):
     row = {"offspring": n}
-    for lpe in (0, 4, 8, 16):
+    for lpe in (0, 4, 8, 16, 32):
         es = HipES("CartPole-v1", 4, 2, True, False, max_step=500, eval_ep_num=5, lanes_per_env=lpe)
         theta = es.perturb(es.zeros(es.P), 0.1, 0, 0, 0, n)
         init = es.init_states_uniform(0, 0, 0, 1, shared=True)[0].contiguous()
