@@ -535,8 +535,13 @@ def rank0_legs(args, result, timer, job, es, world, E, T, skip):
                                           "(chosen by the library's issue-cost model, csrc/ses_rollout.hip)"
                                           if (n_local * E == 20480 and not args.gru) else "chosen by the library"),
                                 "bound": "valu-issue/latency (state and weights in VGPRs, no HBM traffic in the loop)",
-                                "mfma": "not used at eval_ep_num < 12: fp32 MFMA runs at the VALU rate and a 16-column "
-                                        "tile would be 5/16 full (profiles/r01_mfma_vs_valu_gru.txt)"}
+                                "mfma": "not used by this kernel: an MLP step spends ~60 of its 244 instructions on fmas and every offspring has "
+                                        "its own weights.  For the GRU gate contraction (profiles/r06_mfma_vs_valu_gru.txt, both sides of the "
+                                        "contraction): a plain three-register v_fma_f32 issues at HALF the fp32 MFMA rate, but the production form "
+                                        "is v_pk_fma_f32 (input and hidden side in one instruction) at the MFMA rate with no padding -- at the "
+                                        "reference's E = 5 it is at par with v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4x1 blocks, 5 of 8 columns "
+                                        "used: 0.97-1.04 x its time, bit-identical sums) and 1.5 x faster than the 5/16-full 16x16x4 tile; the "
+                                        "4x4x1 form wins from 6 episodes (1.74 x at 8) and is not wired in; the 16x16x4 kernel runs from 12"}
     if args.gru and E >= 12:
         # the GRU rollout runs on v_mfma_f32_16x16x4_f32 from 12 episodes up: 2 fc1 + 96 gate + 8 fc2 tiles per
         # step and 16-episode batch, 2048 flop per tile instruction (padding columns included), fp32 MFMA peak
@@ -604,6 +609,67 @@ def rank0_legs(args, result, timer, job, es, world, E, T, skip):
                 result["rollout_kernel"]["valu_issue_model_note"] = (f"profiles/{models[-1]} prices different machine code of this "
                                                                      "kernel (rerun tools/issue_model.py): not attached")
     timer.end()
+    # ---- the per-GPU populations of the strong line (4096 offspring in total over 2 / 4 / 8 GPUs): ses_rollout alone, and what the
+    # line of record is expected to read at N GPUs from these parts
+    if not args.no_extras and not args.gru and "small_shards" not in skip and E == 5 and T == 500:
+        timer.begin("small_shards")
+        try:
+            small = {}
+            for n_small in (2048, 1024, 512):
+                th_s = es.perturb(es.zeros(es.P), 0.1, 0, 0, 0, n_small)
+                fit_s = es.empty(n_small)
+                for _ in range(20):
+                    es.rollout(th_s, init, mode=job.loop.mode, fitness=fit_s)
+                torch.cuda.synchronize()
+                reps = []
+                for _ in range(9):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        es.rollout(th_s, init, mode=job.loop.mode, fitness=fit_s)
+                    e1.record()
+                    e1.synchronize()
+                    reps.append(e0.elapsed_time(e1) * 100.0)
+                small[str(n_small)] = round(statistics.median(reps), 2)
+            rec = {"rollout_us_by_offspring_per_gpu": small,
+                   "includes": "ses_rollout = the fused rollout kernel + the ~4.4 us episode-mean kernel, 5 episodes x 500 steps",
+                   "note": "512 and 1024 offspring per GPU are FEWER waves than the chip has SIMDs (640 at 16 lanes per env): every wave has "
+                           "its SIMD to itself and the rollout costs 500 x the time ONE wave needs for a step, whatever the population"}
+            models = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_chain_model.json"))
+            if models:
+                cm = json.load(open(os.path.join(ROOT, "profiles", models[-1])))
+                if cm.get("kernel_code_sha256") and cm["kernel_code_sha256"] == kernel_code_hash("k_rollout_cartpole_mlp"):
+                    rec.update({"small_shard_floor_us": cm["chain_ns"] * T * 1e-3,
+                                "lone_wave_inorder_model_us": cm["inorder_ns"] * T * 1e-3,
+                                "lone_wave_issue_only_us": cm["issue_only_ns"] * T * 1e-3,
+                                "chain_model_source": os.path.join("profiles", models[-1]),
+                                "small_shard_floor": "the longest loop-carried dependence cycle of one env step in the 16-lanes-per-env "
+                                                     "loop (obs -> fc1 -> table read -> cubic -> fc2 chain -> DPP tree -> argmax -> force -> "
+                                                     "quotient -> state), every link at the dependent-issue latency measured for a lone wave "
+                                                     "(tools/dep_latency.hip), x 500 steps: no lanes-per-env split of this arithmetic is "
+                                                     "faster (32 lanes per env lengthen it: profiles/r06_small_populations.txt).  "
+                                                     "lone_wave_inorder_model_us: the same graph issued in the listing's order, one "
+                                                     "instruction per 2.2 ns -- what the measured figure should be, and is"})
+                else:
+                    rec["chain_model_note"] = f"profiles/{models[-1]} prices different machine code of this kernel (rerun tools/chain_model.py): not attached"
+            # strong_expected: the generation of record at N GPUs from one-GPU parts = this run's generation with the rollout of
+            # 4096 / N offspring in place of the rollout of 4096, plus one exchange
+            gen_us = result["ms_per_step"] * 1e3
+            full_us = result["rollout_kernel"]["ms"] * 1e3
+            exch_us = 6.4
+            exp = {}
+            for n_gpu, key in ((2, "2048"), (4, "1024"), (8, "512")):
+                us = gen_us - full_us + small[key] + exch_us
+                exp[str(n_gpu)] = {"us_per_generation": round(us, 1), "env_steps_per_s": 4096 * E * T / (us * 1e-6),
+                                   "speedup_vs_1_gpu": round(gen_us / us, 2)}
+            rec["strong_expected"] = dict(exp, parts=f"generation at 1 GPU {gen_us:.1f} us - rollout of 4096 offspring {full_us:.1f} us + rollout of "
+                                                     f"4096 / N offspring + one exchange {exch_us} us (16 KB over the peer-store transport between "
+                                                     "ranks SHARING a GPU, profiles/r04_time_allgather.txt: the flight across xGMI is unmeasured); the "
+                                                     "tail stays replicated at 4096 rows in total (DESIGN section 5)")
+            result["small_shards"] = rec
+        except Exception as exc:
+            result["small_shards_error"] = repr(exc)
+        timer.end()
     # BASELINE.json configs[2]: LunarLanderContinuous-v2 POMDP, GRU policy, 4096 offspring (conf/lunarlander_openai.yaml):
     # one rollout of first-generation policies (sigma = init_sigma around the zero network), episodic
     if not args.no_extras and not args.gru and "c3" not in skip:
