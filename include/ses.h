@@ -89,7 +89,7 @@ int ses_sync(ses_handle *h);
 /* Development / test hook: which of the (result-identical) rollout kernels a handle picks.  Every kernel evaluates the
  * same canonical arithmetic, so no setting changes a result; the defaults are the measured crossovers.  Knobs:
  * "gru_ep_parallel_max" (default 4096), "gru_mfma_min_e" (12), "gru_sequential" (0), "rollout_mix" (1),
- * "rollout_waves8" (1024: light waves of the mixed CartPole MLP split), "rollout_mix_light" (their lanes per env: 0 = choose | 8 | 16), "rollout_lpe32_max_envs" (0: CartPole MLP populations of up to this many envs run at 32 lanes per env), "rollout_block" (64 | 256), "lander_offspring_per_wave" (0 = by population size | 1 | 2 | 4),
+ * "rollout_waves8" (1024: light waves of the mixed CartPole MLP split), "rollout_mix_light" (their lanes per env: 0 = choose | 8 | 16), "rollout_lpe32_max_envs" (0: CartPole MLP populations of up to this many envs run at 32 lanes per env), "rollout_packed" (-1: populations of at most one wave per SIMD run the packed form of the CartPole MLP step | 0: never | 1: whenever 8 or 16 lanes share an env), "rollout_block" (64 | 256), "lander_offspring_per_wave" (0 = by population size | 1 | 2 | 4),
  * "box2d_lanes_per_env" (0 = by population size | 1 | 2 | ... | 64: lanes that share one env in the LunarLander / BipedalWalker MLP rollout),
  * "box2d_envs_per_wave" (0 = by population size | 1 ... 64 / lanes per env: different envs a wave of that rollout carries),
  * "env_step_block" (64 | 128 | 256), "env_step_waves_per_cu" (1 ... 32, default 7) and "env_step_lds_bytes" (-1 ... 65536,
@@ -102,6 +102,8 @@ int ses_sync(ses_handle *h);
  * exchange waits for a peer's shard; 0 = default 60000), "comm_p2p_keep_going" (1: after a time-out later exchanges still
  * run instead of failing; the host polls ses_comm_p2p_status, agrees with the other ranks and rolls back -- ESLoop.run()),
  * "openai_sharded_tail" (default 1; 0: ses_openai_sharded_ok answers no, sharded runs keep the replicated openai_es tail),
+ * "openai_sharded_min_rows" (default 8192: populations of fewer rows IN TOTAL keep the replicated tail -- the shard form costs a
+ * second exchange and measured slower at 4096 rows in total),
  * "openai_granule_exchange" (default 1; 0: ses_openai_generation_sharded all-gathers its chunk partials with a launch of their
  * own also on the peer-store transport, as it does over RCCL -- for measuring one against the other),
  * "comm_granule_allgather" (default 0; 1: ses_allgather_fitness over the peer-store transport moves 8-byte {exchange number,

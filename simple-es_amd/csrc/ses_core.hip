@@ -120,6 +120,7 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     h->tune_gru_sequential = 0;
     h->tune_rollout_mix = 1;
     h->tune_rollout_waves8 = 1024;
+    h->tune_rollout_packed = -1;
     h->tune_lander_per_wave = 0;
     h->tune_box2d_lpe = 0;
     h->tune_box2d_epw = 0;
@@ -137,6 +138,7 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
         h->lds_per_cu = lds;
     }
     h->tune_openai_sharded_tail = 1;
+    h->tune_openai_sharded_min_rows = 8192;
     h->tune_openai_granules = 1;
     h->tune_comm_granules_enabled = 1;
     h->tune_fused_fitness = 1;
@@ -165,6 +167,7 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"rollout_waves8", &ses_handle::tune_rollout_waves8, 1, 1 << 20},
                                  {"rollout_mix_light", &ses_handle::tune_rollout_mix_light, 0, 16},
                                  {"rollout_lpe32_max_envs", &ses_handle::tune_rollout_lpe32_max, 0, 1 << 30},
+                                 {"rollout_packed", &ses_handle::tune_rollout_packed, -1, 1},
                                  {"lander_offspring_per_wave", &ses_handle::tune_lander_per_wave, 0, 4},
                                  {"box2d_lanes_per_env", &ses_handle::tune_box2d_lpe, 0, 64},
                                  {"box2d_envs_per_wave", &ses_handle::tune_box2d_epw, 0, 64},
@@ -176,6 +179,7 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"comm_p2p_timeout_ms", &ses_handle::tune_comm_p2p_timeout_ms, 0, 1 << 30},
                                  {"comm_p2p_keep_going", &ses_handle::tune_comm_p2p_keep_going, 0, 1},
                                  {"openai_sharded_tail", &ses_handle::tune_openai_sharded_tail, 0, 1},
+                                 {"openai_sharded_min_rows", &ses_handle::tune_openai_sharded_min_rows, 0, 1 << 30},
                                  {"openai_granule_exchange", &ses_handle::tune_openai_granules, 0, 1},
                                  {"comm_granule_allgather", &ses_handle::tune_comm_granules, 0, 1},
                                  {"comm_granules_enabled", &ses_handle::tune_comm_granules_enabled, 0, 1},

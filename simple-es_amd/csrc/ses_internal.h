@@ -35,6 +35,7 @@ struct ses_handle {
     int tune_rollout_waves8;       // light waves of the mixed split
     int tune_rollout_mix_light;    // lanes per env of the light waves: 0 = choose, 8, 16
     int tune_rollout_lpe32_max;    // CartPole MLP populations of up to this many envs run at 32 lanes per env (0: never)
+    int tune_rollout_packed;       // the packed step of lone waves (ses_policy_pk.h): -1 = when every wave has a SIMD to itself, 0 / 1
     // ses_set_stamp: where the next stamped launch of this handle writes the GPU real-time counter (or null)
     unsigned long long *stamp;
     // ses_openai_generation: the rank vector in red_scratch that is known to be zero (left so by the update kernel)
@@ -82,6 +83,7 @@ struct ses_handle {
     int tune_openai_granules;      // 0: the shard form all-gathers its chunk partials as floats with a launch of its own also on the
                                    // peer-store transport (default 1: {sequence, value} granules stored by the gradient kernel itself)
     int tune_openai_sharded_tail;  // 0: ses_openai_sharded_ok says no (sharded runs use the replicated openai_es tail; A/B runs)
+    int tune_openai_sharded_min_rows; // populations below this many rows IN TOTAL keep the replicated tail (default 8192)
 };
 
 namespace ses {

@@ -11,6 +11,7 @@
 #include "ses_walker.h"
 #include "ses_internal.h"
 #include "ses_policy.h"
+#include "ses_policy_pk.h"
 #include "ses_spread.h"
 
 namespace ses {
@@ -132,7 +133,8 @@ __device__ __forceinline__ void rollout_cartpole_mlp_loop(const TanhEntry *tanh_
 }
 
 // One wave's share of the rollout: envs [env0 + wave_local_index ...), LPE lanes per env.
-template <int LPE, bool FIXED_LENGTH, bool PHYS64 = false>
+// PK: the packed form of the step for a wave that has its SIMD to itself (ses_policy_pk.h; LPE 8 or 16, fp32 dynamics).
+template <int LPE, bool FIXED_LENGTH, bool PHYS64 = false, bool PK = false>
 __device__ __forceinline__ void rollout_cartpole_mlp_body(const TanhEntry *tanh_tab, long long lane_index, int env0,
                                                           const float *__restrict__ theta,
                                                           const float *__restrict__ init, int init_per_offspring,
@@ -140,39 +142,52 @@ __device__ __forceinline__ void rollout_cartpole_mlp_body(const TanhEntry *tanh_
                                                           double *__restrict__ ep_return,
                                                           int32_t *__restrict__ ep_steps)
 {
+    static_assert(!PK || (!PHYS64 && (LPE == 8 || LPE == 16)), "the packed step exists for 8 / 16 lanes per env, fp32 dynamics");
     int env = env0 + (int)(lane_index / LPE);
     const int sub = (int)(lane_index % LPE);
     const bool valid = env < n_env;
     env = valid ? env : n_env - 1;  // keep every lane active (DPP needs full waves); only valid lanes store
     const int row = env / E;
     const int ep = env - row * E;
-
-    MlpSlice<4, 2, LPE> net;
-    net.load(theta + (size_t)row * P, sub);
-
     const float *s0 = init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 4;
-    CartPoleSim<PHYS64> sim;
-    sim.init(s0);
     int steps = 0;
     // Loop variants, chosen once per wave (both conditions are wave-uniform):
     //  * fully observed envs (obs_mask == 0, a kernel argument) skip the four masking selects per step;
     //  * when every lane starts inside |th| <= 0.78 -- resets are U(-0.05, 0.05) -- the angle stays there for the
     //    whole episode (CP_TH_CLAMP) and the sin/cos argument reduction is skipped, bit-identically (sincos_small_);
     //    a caller-supplied initial state outside that range runs the general loop.
-    const bool small = !PHYS64 && __ballot(!sim.small_angle()) == 0ull;
-    if (obs_mask == 0u && small)
-        rollout_cartpole_mlp_loop<LPE, FIXED_LENGTH, PHYS64, false, true>(tanh_tab, net, sim, max_step, obs_mask, steps);
-    else if (small)
-        rollout_cartpole_mlp_loop<LPE, FIXED_LENGTH, PHYS64, true, true>(tanh_tab, net, sim, max_step, obs_mask, steps);
-    else
-        rollout_cartpole_mlp_loop<LPE, FIXED_LENGTH, PHYS64, true, false>(tanh_tab, net, sim, max_step, obs_mask, steps);
+    const bool small = !PHYS64 && __ballot(!(__builtin_fabsf(s0[2]) <= SINCOS_SMALL_MAX)) == 0ull;
+    bool done = false;
+    if constexpr (PK) {
+        if (small) {
+            MlpSlicePk<LPE> netp;
+            netp.load(theta + (size_t)row * P, sub);
+            if (obs_mask == 0u)
+                rollout_cartpole_mlp_loop_pk<LPE, FIXED_LENGTH, false>(tanh_tab, netp, s0, max_step, obs_mask, steps);
+            else
+                rollout_cartpole_mlp_loop_pk<LPE, FIXED_LENGTH, true>(tanh_tab, netp, s0, max_step, obs_mask, steps);
+            done = true;
+        }
+    }
+    if (!done) {
+        MlpSlice<4, 2, LPE> net;
+        net.load(theta + (size_t)row * P, sub);
+        CartPoleSim<PHYS64> sim;
+        sim.init(s0);
+        if (obs_mask == 0u && small)
+            rollout_cartpole_mlp_loop<LPE, FIXED_LENGTH, PHYS64, false, true>(tanh_tab, net, sim, max_step, obs_mask, steps);
+        else if (small)
+            rollout_cartpole_mlp_loop<LPE, FIXED_LENGTH, PHYS64, true, true>(tanh_tab, net, sim, max_step, obs_mask, steps);
+        else
+            rollout_cartpole_mlp_loop<LPE, FIXED_LENGTH, PHYS64, true, false>(tanh_tab, net, sim, max_step, obs_mask, steps);
+    }
     if (valid && sub == 0) {
         if (ep_return) ep_return[env] = (double)steps;  // CartPole reward is 1 per step incl. the terminal one
         if (ep_steps) ep_steps[env] = steps;
     }
 }
 
-template <int LPE, bool FIXED_LENGTH, int BLOCK, bool PHYS64 = false>
+template <int LPE, bool FIXED_LENGTH, int BLOCK, bool PHYS64 = false, bool PK = false>
 __global__ __launch_bounds__(BLOCK) void k_rollout_cartpole_mlp(const float *__restrict__ theta,
                                                              const float *__restrict__ init, int init_per_offspring,
                                                              int n_rows, int E, int P, int max_step,
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_cartpole_mlp(const float *__r
 {
     __shared__ TanhEntry tanh_tab[SES_TANH_N];
     stage_tanh_table(tanh_tab);
-    rollout_cartpole_mlp_body<LPE, FIXED_LENGTH, PHYS64>(tanh_tab, (long long)blockIdx.x * BLOCK + threadIdx.x, 0, theta, init,
+    rollout_cartpole_mlp_body<LPE, FIXED_LENGTH, PHYS64, PK>(tanh_tab, (long long)blockIdx.x * BLOCK + threadIdx.x, 0, theta, init,
                                                  init_per_offspring, n_rows * E, E, P, max_step, obs_mask, ep_return,
                                                  ep_steps);
 }
@@ -1093,26 +1108,41 @@ static int pick_lanes_per_env(const ses_handle *h, long long n_env)
     return n_env <= 4096 ? 16 : 8;
 }
 
-template <int LPE, int BLOCK>
+template <int LPE, int BLOCK, bool PK = false>
 static void launch_rollout_b(const ses_handle *h, const float *theta, const float *init, int per, int n_rows, int mode,
                              double *ep_return, int32_t *ep_steps)
 {
     const long long threads = (long long)n_rows * h->cfg.eval_ep_num * LPE;
     const int blocks = ceil_div(threads, BLOCK);
     if (mode == SES_MODE_FIXED_LENGTH)
-        hipLaunchKernelGGL((k_rollout_cartpole_mlp<LPE, true, BLOCK>), dim3(blocks), dim3(BLOCK), 0, h->stream, theta,
+        hipLaunchKernelGGL((k_rollout_cartpole_mlp<LPE, true, BLOCK, false, PK>), dim3(blocks), dim3(BLOCK), 0, h->stream, theta,
                            init, per, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, ep_return,
                            ep_steps);
     else
-        hipLaunchKernelGGL((k_rollout_cartpole_mlp<LPE, false, BLOCK>), dim3(blocks), dim3(BLOCK), 0, h->stream, theta,
+        hipLaunchKernelGGL((k_rollout_cartpole_mlp<LPE, false, BLOCK, false, PK>), dim3(blocks), dim3(BLOCK), 0, h->stream, theta,
                            init, per, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, ep_return,
                            ep_steps);
+}
+
+// The packed step (ses_policy_pk.h) pays where a wave has its SIMD to itself: populations of at most one wave per SIMD at the
+// chosen lanes per env.  ses_set_tuning "rollout_packed": -1 = this rule (default), 0 = never, 1 = whenever the split is 8 or 16.
+static bool cartpole_mlp_packed(const ses_handle *h, int lpe, long long episodes)
+{
+    if (lpe != 8 && lpe != 16) return false;
+    if (h->tune_rollout_packed >= 0) return h->tune_rollout_packed != 0;
+    return ceil_div(episodes * lpe, 64) <= h->tune_rollout_waves8;          // (the knob holds the chip's SIMD count: 1024)
 }
 
 template <int LPE>
 static void launch_rollout(const ses_handle *h, const float *theta, const float *init, int per, int n_rows, int mode,
                            double *ep_return, int32_t *ep_steps)
 {
+    if constexpr (LPE == 8 || LPE == 16) {
+        if (h->tune_rollout_block != 256 && cartpole_mlp_packed(h, LPE, (long long)n_rows * h->cfg.eval_ep_num)) {
+            launch_rollout_b<LPE, 64, true>(h, theta, init, per, n_rows, mode, ep_return, ep_steps);
+            return;
+        }
+    }
     if (h->tune_rollout_block == 256) launch_rollout_b<LPE, 256>(h, theta, init, per, n_rows, mode, ep_return, ep_steps);
     else launch_rollout_b<LPE, 64>(h, theta, init, per, n_rows, mode, ep_return, ep_steps);
 }

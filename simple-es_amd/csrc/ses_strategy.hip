@@ -1216,6 +1216,11 @@ int ses_openai_sharded_ok(ses_handle *h, ses_handle *comm, int32_t n, int32_t pe
 {
     SES_REQUIRE(h && comm, "ses_openai_sharded_ok: null handle");
     if (!h->tune_openai_sharded_tail || n < 2 || world < 2 || per_rank < ES_CHUNK || per_rank % ES_CHUNK != 0) return 0;
+    // Round 6: the shard form costs a second exchange, and below 8192 rows in total the replicated tail is four ~5 us launches
+    // whatever part of it a rank skips: 4096 rows in total (BASELINE's metric as written) measured 21.5 / 17.5 us replicated against
+    // 20.2 / 19.5 us in shard form at 2 / 4 ranks, exchanges between ranks that SHARE a GPU, i.e. without the xGMI flight
+    // (profiles/r06_time_tail_strong.txt); from 8192 rows the shard form wins (24.8 against 29.0 us at 2 x 4096).
+    if (n < h->tune_openai_sharded_min_rows) return 0;
     if ((long long)per_rank * (world - 1) >= n || (long long)per_rank * world < n) return 0;   // per_rank = ceil(n / world): every rank owns rows
     if (comm->stream != h->stream || comm->cfg.device != h->cfg.device) return 0;
     const int quads = (h->P + 3) / 4, cl = per_rank / ES_CHUNK;

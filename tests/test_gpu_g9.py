@@ -41,7 +41,8 @@ def test_g9_cartpole_mlp(g9, lpe):
     theta, init = g9["mlp_theta"], g9["init_states"]
     o_fit, o_ret, o_steps = co.rollout_cartpole(theta, init, 5, 500)
     es = HipES("CartPole-v1", 4, 2, True, False, max_step=500, eval_ep_num=5, lanes_per_env=lpe)
-    for mode in (0, 1):
+    for mode, packed in [(m, k) for m in (0, 1) for k in ((0, 1) if lpe in (0, 16) else (0,))]:
+        es.set_tuning("rollout_packed", packed)                      # the scalar step and the packed step of lone waves
         fit, ep_ret, ep_steps = es.rollout(dev(theta), dev(init), mode=mode, want_episodes=True)
         assert np.array_equal(host(ep_steps), o_steps), f"mode {mode}"
         assert np.array_equal(bits(host(fit)), bits(o_fit)) and np.array_equal(host(ep_ret), o_ret)

@@ -296,7 +296,9 @@ def test_rollout_golden_g5_and_oracle(golden_dir, lpe):
     theta, init = g["g5_theta"], g["init_states"]
     h = HipES("CartPole-v1", 4, 2, True, False, max_step=500, eval_ep_num=5, lanes_per_env=lpe)
     o_fit, o_ret, o_steps = co.rollout_cartpole(theta, init, 5, 500)
-    for mode in (0, 1):
+    # (8 / 16 lanes per env and the library's own choice: the scalar step and the packed step of lone waves, ses_policy_pk.h)
+    for mode, packed in [(m, k) for m in (0, 1) for k in ((0, 1) if lpe in (0, 8, 16) else (0,))]:
+        h.set_tuning("rollout_packed", packed)
         fit, ep_ret, ep_steps = h.rollout(dev(theta), dev(init), mode=mode, want_episodes=True)
         assert np.array_equal(host(ep_steps), o_steps), f"mode {mode}: episode lengths differ from the oracle"
         assert_bit_equal(host(fit), o_fit, "fitness")
@@ -339,7 +341,8 @@ def test_rollout_wild_initial_states_take_the_general_loop(lpe):
         h = HipES("CartPole-v1", 4, 2, True, False, pomdp=pomdp, max_step=300, eval_ep_num=5, lanes_per_env=lpe)
         o_fit, _, o_steps = co.rollout_cartpole(theta, init, 5, 300, obs_mask=mask)
         assert (o_steps.reshape(n, 5)[wild] > 1).any()                # some wild starts survive the first step
-        for mode in (0, 1):
+        for mode, packed in [(m, k) for m in (0, 1) for k in ((0, 1) if lpe in (0, 8, 16) else (0,))]:
+            h.set_tuning("rollout_packed", packed)                    # (a packed wave with a wild start falls back to the general loop)
             fit, _, ep_steps = h.rollout(dev(theta), dev(init), mode=mode, want_episodes=True)
             assert np.array_equal(host(ep_steps), o_steps), (pomdp, mode)
             assert_bit_equal(host(fit), o_fit, f"pomdp={pomdp} mode={mode}")

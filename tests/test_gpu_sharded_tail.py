@@ -30,6 +30,7 @@ WORKER = textwrap.dedent("""
     P = ref.P
     for r, es in enumerate(ranks):
         es.set_tuning("comm_p2p_timeout_ms", 5000)
+        es.set_tuning("openai_sharded_min_rows", 0)          # (the product keeps populations below 8192 rows replicated: round 6)
         es.set_tuning("openai_granule_exchange", granules)   # 1: the gradient kernel stores {sequence, value} granules into the
                                                              # peers' mailboxes and the update polls them; 0: float all-gather launch
         es.comm_p2p_export(r, world, 65536)

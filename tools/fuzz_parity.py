@@ -59,6 +59,7 @@ def sharded_tail_case(rng, force=None):
         granules = force.get("granules", granules)
     for r, es in enumerate(ranks):
         es.set_tuning("comm_p2p_timeout_ms", 20000)
+        es.set_tuning("openai_sharded_min_rows", 0)               # the fuzz covers the shard form at every aligned size
         es.set_tuning("openai_granule_exchange", granules)
         es.comm_p2p_export(r, world, 65536)
     for es in ranks:
@@ -206,6 +207,7 @@ def main():
             n, E, T = int(rng.choice([1, 3, 17, 64, 129, 700, 1700, 2100])), int(rng.randint(1, 8)), int(rng.choice([1, 7, 60, 200]))
             pomdp, lpe, p64 = bool(rng.randint(0, 2)), int(rng.choice([0, 0, 1, 2, 4, 8, 16, 32])), bool(rng.rand() < 0.15)
             es = HipES("CartPole-v1", 4, 2, True, False, pomdp=pomdp, max_step=T, eval_ep_num=E, lanes_per_env=lpe, physics64=p64)
+            es.set_tuning("rollout_packed", int(rng.choice([-1, 0, 1])))      # the packed step of lone waves: by rule, never, always
             theta = (rng.randn(n, 226) * sigma).astype(np.float32)
             init = rng.uniform(-0.05, 0.05, (E, 4) if shared else (n, E, 4)).astype(np.float32)
             if rng.rand() < 0.2:
