@@ -633,8 +633,9 @@ def rank0_legs(args, result, timer, job, es, world, E, T, skip):
                 small[str(n_small)] = round(statistics.median(reps), 2)
             rec = {"rollout_us_by_offspring_per_gpu": small,
                    "includes": "ses_rollout = the fused rollout kernel + the ~4.4 us episode-mean kernel, 5 episodes x 500 steps",
-                   "note": "512 and 1024 offspring per GPU are FEWER waves than the chip has SIMDs (640 at 16 lanes per env): every wave has "
-                           "its SIMD to itself and the rollout costs 500 x the time ONE wave needs for a step, whatever the population"}
+                   "note": "512 and 1024 offspring per GPU are FEWER waves than the chip has SIMDs (640 at 16 / 8 lanes per env): every wave has "
+                           "its SIMD to itself and the rollout costs 500 x the time ONE wave needs for a step, whatever the population; such "
+                           "waves run the packed form of the step (csrc/ses_policy_pk.h, round 6: 105 -> 94 us at 512, 126 -> 115 us at 1024)"}
             models = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_chain_model.json"))
             if models:
                 cm = json.load(open(os.path.join(ROOT, "profiles", models[-1])))
@@ -649,7 +650,9 @@ def rank0_legs(args, result, timer, job, es, world, E, T, skip):
                                                      "(tools/dep_latency.hip), x 500 steps: no lanes-per-env split of this arithmetic is "
                                                      "faster (32 lanes per env lengthen it: profiles/r06_small_populations.txt).  "
                                                      "lone_wave_inorder_model_us: the same graph issued in the listing's order, one "
-                                                     "instruction per 2.2 ns -- what the measured figure should be, and is"})
+                                                     "instruction per 2.2 ns, every dependent link at its full back-to-back latency -- an "
+                                                     "estimate (the scalar loop: 207 ns modelled, 198 measured; the packed loop: 209 against "
+                                                     "176 -- links with other instructions between them cost less than back to back)"})
                 else:
                     rec["chain_model_note"] = f"profiles/{models[-1]} prices different machine code of this kernel (rerun tools/chain_model.py): not attached"
             # strong_expected: the generation of record at N GPUs from one-GPU parts = this run's generation with the rollout of

@@ -132,16 +132,8 @@ struct MlpSlice {
             idx[u] = tanh_index_scaled(acc, pd.frac[u]);
         }
         __builtin_amdgcn_sched_barrier(0);
-#if defined(SES_EXPERIMENT_TANH_NO_CONFLICT)
-        // TIMING EXPERIMENT ONLY (tools/ab_tanh_conflicts.sh; results are wrong): lane l reads an entry whose index is l mod 16
-        // in its low four bits, so the 16 lanes of an LDS pass hit 16 different 16-byte bank groups -- what a conflict-free
-        // table layout would cost at best, with the instruction stream unchanged (one v_bfi per read added)
-#pragma unroll
-        for (int u = 0; u < U; ++u) pd.ent[u] = tab[(idx[u] & ~15) | (int)(threadIdx.x & 15u)];
-#else
 #pragma unroll
         for (int u = 0; u < U; ++u) pd.ent[u] = tab[idx[u]];
-#endif
     }
 
     __device__ __forceinline__ void finish(const Pending &pd, float (&logits)[A]) const

@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_policy_forward_gru(const float *__restr
 static int pick_lanes_per_env(const ses_handle *h, long long n_env)
 {
     if (h->cfg.lanes_per_env) return h->cfg.lanes_per_env;
-    // Measured on MI355X (tools/sweep_lpe.sh): 4 lanes per env wins from 20 480 envs (1280 waves) up to
+    // Measured on MI355X (round 1 sweep, profiles/r01_rollout_occupancy_sweep.txt): 4 lanes per env wins from 20 480 envs (1280 waves) up to
     // 327 680 envs; below ~10 000 envs only LPE = 8 still gives every SIMD a wavefront, and while even that leaves the
     // population within one wave per SIMD (4096 envs) 16 lanes per env make the lone wave's step shorter still
     // (83 instead of 104 instructions: conf/cartpole.yaml's 480 envs are 500 sequential steps of such a wave).
@@ -1225,7 +1225,7 @@ static int lander_offspring_per_wave(const ses_handle *h, int n_rows)
 
 // Which split of the lanes runs a CartPole MLP population of `episodes` envs.  Every split evaluates the same canonical
 // arithmetic; what differs is how much the busiest SIMD has to issue per env step and with how many waves it shares the
-// issue port.  Model (tools/ab_mix_light.py, MI355X): a wave's loop body is 160 / 104 / 84 VALU instructions at 4 / 8 / 16
+// issue port.  Model (profiles/r03_ab_mix_light.txt, MI355X): a wave's loop body is 160 / 104 / 84 VALU instructions at 4 / 8 / 16
 // lanes per env; a SIMD that holds k waves issues one of their instructions every 5.0 / 3.45 / 3.1 / 2.95 cycles (k = 1,
 // 2, 3, >= 4: a lone wave waits for its own dependences).  Candidates: the pure splits, and "one light wave per SIMD
 // (8 or 16 lanes per env) + the rest at 4 lanes per env".  Measured against the model at 3072 / 4096 / 5120 offspring x 5
@@ -1241,7 +1241,7 @@ static MlpSplit choose_cartpole_mlp_split(const ses_handle *h, long long episode
     // round 6: 32 lanes per env (77 VALU instructions per step against 83 at 16, but two more dependent steps in fc2) -- a knob,
     // off by default: profiles/r06_small_populations.txt has the A/B that decides it
     if (h->tune_rollout_lpe32_max > 0 && episodes <= h->tune_rollout_lpe32_max) return MlpSplit{0, 32};
-    if (episodes > 49152) return MlpSplit{0, 4};                       // large populations: 4 lanes per env (tools/sweep_lpe.sh)
+    if (episodes > 49152) return MlpSplit{0, 4};                       // large populations: 4 lanes per env (round 1 sweep)
     const int simds = h->tune_rollout_waves8;                           // 1024 = 256 CUs x 4 (knob: the light waves of a mix)
     auto instr = [](int lpe) { return lpe == 4 ? 160.0 : (lpe == 8 ? 104.0 : 84.0); };
     auto cadence = [](long long k) { return k <= 1 ? 5.0 : (k == 2 ? 3.45 : (k == 3 ? 3.1 : 2.95)); };

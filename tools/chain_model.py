@@ -4,7 +4,8 @@ populations (512 / 1024 offspring per GPU of the strong-scaling line: fewer wave
 
     python tools/chain_model.py profiles/r06_chain_model.json [profiles/r06_dep_latency.json]
 
-From the gfx950 listing of `k_rollout_cartpole_mlp<16, fixed length>` (the loop a 512-offspring shard runs) the tool builds the
+From the gfx950 listing of `k_rollout_cartpole_mlp<16, fixed length, packed>` (the loop a 512-offspring shard runs; the scalar twin
+is priced beside it) the tool builds the
 register dependence graph of the loop body -- every VGPR / SGPR / vcc read and write, the loop-carried ones included -- and
 prices it with the latencies tools/dep_latency.hip measured on MI355X for a lone wave (issue-to-issue time of DEPENDENT
 instructions, per kind; ~3.6-3.9 ns for plain VALU, 25 ns for the table's ds_read_b128):
@@ -30,7 +31,7 @@ sys.path.insert(0, HERE)
 import kernel_hash  # noqa: E402
 from issue_model import build_flags  # noqa: E402
 
-KERNEL = "k_rollout_cartpole_mlpILi16ELb1ELi64ELb0"
+KERNEL = "k_rollout_cartpole_mlpILi16ELb1ELi64ELb0ELb1"      # <16 lanes per env, fixed length, 64-thread workgroups, fp32, PACKED>: what a 512-offspring shard runs
 
 
 def regs_of(tok):
@@ -177,18 +178,25 @@ def main():
            "v_rcp_f32": ns("v_rcp_f32"), "dpp": ns("v_add_f32_dpp row_ror"), "cmp": pair / 2, "cndmask": pair / 2,
            # the measured link is add + read + wait + mov: the read's own share is the link minus two plain VALU links
            "lds_read": lds_link - 2 * ns("v_lshlrev_b32"), "salu": 0.5}
+    for pk, scalar in (("v_pk_fma_f32", "v_fma_f32"), ("v_pk_mul_f32", "v_mul_f32"), ("v_pk_add_f32", "v_add_f32")):
+        lat[pk] = dep[pk]["ns"] if pk in dep else lat[scalar]               # (older latency files have no packed links)
     issue_ns = 2.2                                                          # profiles/r01_valu_issue.txt, one wave per SIMD
     with tempfile.TemporaryDirectory() as tmp:
         lst = os.path.join(tmp, "rollout.s")
         src = os.path.join(ROOT, "simple-es_amd", "csrc", "ses_rollout.hip")
         subprocess.check_call(["/opt/rocm/bin/hipcc"] + build_flags() + ["--cuda-device-only", "-S", src, "-o", lst],
                               stderr=subprocess.DEVNULL)
-        name, best = loop_body(open(lst).read().splitlines(), KERNEL)
+        text = open(lst).read().splitlines()
+        name, best = loop_body(text, KERNEL)
+        _, twin = loop_body(text, KERNEL[:-4] + "ELb0")
     ins, _, label, valu = best
     chain, inorder = simulate(ins, lat, issue_ns)
+    twin_chain, twin_inorder = simulate(twin[0], lat, issue_ns)
     lib = os.path.join(ROOT, "simple-es_amd", "libses_hip.so")
-    model = {"kernel": name, "loop": label, "valu_instructions": valu, "lds_reads": sum(1 for p in ins if p[3] == "lds"),
+    model = {"kernel": name, "kernel_match": "k_rollout_cartpole_mlp", "loop": label, "valu_instructions": valu, "lds_reads": sum(1 for p in ins if p[3] == "lds"),
              "chain_ns": round(chain, 2), "inorder_ns": round(inorder, 2), "issue_ns": issue_ns,
+             "scalar_twin": {"loop": twin[2], "valu_instructions": twin[3], "chain_ns": round(twin_chain, 2),
+                             "inorder_ns": round(twin_inorder, 2)},
              "issue_only_ns": round(issue_ns * (valu + sum(1 for p in ins if p[3] == "lds")), 2),
              "kernel_code_sha256": kernel_hash.hash_kernels(lib, "k_rollout_cartpole_mlp"),
              "latencies_ns": {k: round(v, 3) for k, v in lat.items()}, "latency_source": os.path.relpath(dep_path, ROOT),

@@ -12,6 +12,8 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 #define R8(OP) OP OP OP OP OP OP OP OP
 #define BODY32(OP) R8(OP) R8(OP) R8(OP) R8(OP)
 
@@ -23,10 +25,12 @@
         __syncthreads();                                                                                           \
         float r = seed * (1 + (threadIdx.x & 3)), a = 1.0f + seed * 1e-3f, b = seed * 1e-3f;                       \
         float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;                                                           \
+        v2f p2 = {r, r * 0.5f}, a2 = {a, a}, b2 = {b, b};                                                            \
+        (void)a2; (void)b2;                                                                                         \
         unsigned addr = (unsigned)(size_t)lds;                                                                      \
         (void)q0; (void)q1; (void)q2; (void)q3; (void)addr;                                                         \
         for (int it = 0; it < iters; ++it) { BODY32(ASM) }                                                         \
-        out[blockIdx.x * blockDim.x + threadIdx.x] = r + q0 + q1 + q2 + q3 + (float)addr;                          \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = r + q0 + q1 + q2 + q3 + (float)addr + p2.x + p2.y;            \
     }
 
 #define L_FMA asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r) : "v"(a), "v"(b));
@@ -54,7 +58,13 @@
                            : "+v"(r), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(addr) : : "v100", "v101", "v102", "v103");
 #define L_SWAP16 asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1\n\tv_add_f32_e32 %0, %0, %1" : "+v"(r), "+v"(q0));
 
+#define L_PKFMA asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p2) : "v"(a2), "v"(b2));
+#define L_PKMUL asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p2) : "v"(a2));
+#define L_PKADD asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p2) : "v"(b2));
 KERNEL(k_fma, L_FMA)
+KERNEL(k_pkfma, L_PKFMA)
+KERNEL(k_pkmul, L_PKMUL)
+KERNEL(k_pkadd, L_PKADD)
 KERNEL(k_fmac, L_FMAC)
 KERNEL(k_fmamk, L_FMAMK)
 KERNEL(k_mul, L_MUL)
@@ -81,7 +91,7 @@ int main()
 {
     struct Case { const char *name; kern_t k; int instr_per_link; };
     const std::vector<Case> cases = {
-        {"v_fma_f32", k_fma, 1}, {"v_fmac_f32", k_fmac, 1}, {"v_fmamk_f32", k_fmamk, 1}, {"v_mul_f32", k_mul, 1}, {"v_add_f32", k_add, 1},
+        {"v_fma_f32", k_fma, 1}, {"v_pk_fma_f32", k_pkfma, 1}, {"v_pk_mul_f32", k_pkmul, 1}, {"v_pk_add_f32", k_pkadd, 1}, {"v_fmac_f32", k_fmac, 1}, {"v_fmamk_f32", k_fmamk, 1}, {"v_mul_f32", k_mul, 1}, {"v_add_f32", k_add, 1},
         {"v_add_f32_dpp quad_perm", k_add_dpp_q, 1}, {"v_add_f32_dpp row_ror", k_add_dpp_r, 1}, {"v_mov_b32_dpp row_newbcast", k_mov_dpp, 1},
         {"v_mul_f32_dpp quad_perm", k_mul_dpp, 1}, {"v_min_f32 |x|", k_min, 1}, {"v_cvt_i32_f32", k_cvt, 1}, {"v_fract_f32", k_fract, 1},
         {"v_lshlrev_b32", k_lshl, 1}, {"v_bfi_b32", k_bfi, 1}, {"v_med3_f32", k_med3, 1}, {"v_rcp_f32", k_rcp, 1},

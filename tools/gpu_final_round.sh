@@ -5,7 +5,7 @@
 # lines, loop timings.   usage: tools/gpu_final_round.sh [round tag = r03] [fuzz seconds per process = 240]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-TAG=${1:-r05}
+TAG=${1:-r06}
 FUZZ=${2:-240}
 OUT=gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
@@ -49,6 +49,11 @@ SES_OUT=$R/ab/libT.so SES_OBJ=/tmp/objT bash simple-es_amd/csrc/build.sh -DSES_P
 for w in walker lander c3; do SES_LIB_PATH=$R/ab/libT.so python tools/walker_phases.py $w 4096 2>/dev/null; done > $OUT/${TAG}_step_phases.txt
 python tools/c3_breakdown.py > $OUT/${TAG}_c3_by_horizon.txt 2>&1
 python tools/time_small_populations.py 2>/dev/null > $OUT/${TAG}_small_populations.txt
+# round 6: dependent-issue latencies of a lone wave (input of tools/chain_model.py), the MFMA forms of the GRU gate contraction, the
+# tail of the strong line (4096 rows in total) by GPU count
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/dep_latency.hip -o tools/dep_latency 2>/dev/null && tools/dep_latency > $OUT/${TAG}_dep_latency.json
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize tools/mfma_vs_valu_gru.hip -o tools/mfma_vs_valu_gru 2>/dev/null && tools/mfma_vs_valu_gru > $OUT/${TAG}_mfma_vs_valu_gru.txt
+SES_TAIL_SHAPES=1x4096,2x2048,4x1024,8x512 python tools/time_tail.py 2>/dev/null > $OUT/${TAG}_time_tail_strong.txt; cat $OUT/${TAG}_time_tail_strong.txt
 python tools/lander_step_cost.py > $OUT/${TAG}_lander_step_cost.txt 2>&1
 # the multi-rank side (tests excluded: they ran above): exchange latency by kind, a generation of two ranks with and without the
 # fused exchanges, the openai_es tail replicated / in shard form, the 8-rank shapes by kernel
@@ -57,7 +62,7 @@ for f in time_allgather time_multirank_generation time_tail_sharded tail_by_kern
 # bench.py --gpus 2 / 4 rehearsed with the ranks sharing this GPU (gloo control plane, peer-store transport): the multi-rank
 # code path of the bench, NOT a scaling measurement
 for n in 2 4; do
-  SES_BENCH_BACKEND=gloo timeout -k 10 500 python bench.py --gpus $n --steps 100 --warmup 20 --blocks 9 --no-roofline --no-cpu-baseline --loop-generations 300 > $OUT/${TAG}_bench_rehearsal_gloo_${n}ranks_one_gpu.json 2>> $OUT/bench.err
+  SES_BENCH_BACKEND=gloo timeout -k 10 500 python bench.py --gpus $n --steps 100 --warmup 20 --blocks 9 --min-timed-seconds 2 --no-roofline --no-cpu-baseline --loop-generations 300 > $OUT/${TAG}_bench_rehearsal_gloo_${n}ranks_one_gpu.json 2>> $OUT/bench.err
 done
 # gpurun copies gpurun_out/ back only below 64 MiB: the raw rocprofv3 directories stay on the box
 find gpurun_out -mindepth 1 -maxdepth 1 ! -name final -exec rm -rf {} +
