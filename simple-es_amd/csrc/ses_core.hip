@@ -121,6 +121,7 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     h->tune_rollout_mix = 1;
     h->tune_rollout_waves8 = 1024;
     h->tune_rollout_packed = -1;
+    h->tune_rollout_mix_8_16 = 1;
     h->tune_lander_per_wave = 0;
     h->tune_box2d_lpe = 0;
     h->tune_box2d_epw = 0;
@@ -161,6 +162,7 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
     };
     static const Knob knobs[] = {{"rollout_block", &ses_handle::tune_rollout_block, 64, 256},
                                  {"gru_mfma_min_e", &ses_handle::tune_gru_mfma_min_e, 1, 1 << 30},
+                                 {"gru_mfma4_min_e", &ses_handle::tune_gru_mfma4_min_e, 0, 8},
                                  {"gru_ep_parallel_max", &ses_handle::tune_gru_ep_parallel_max, 0, 1 << 30},
                                  {"gru_sequential", &ses_handle::tune_gru_sequential, 0, 1},
                                  {"rollout_mix", &ses_handle::tune_rollout_mix, 0, 1},
@@ -168,6 +170,7 @@ int ses_set_tuning(ses_handle *h, const char *name, int32_t value)
                                  {"rollout_mix_light", &ses_handle::tune_rollout_mix_light, 0, 16},
                                  {"rollout_lpe32_max_envs", &ses_handle::tune_rollout_lpe32_max, 0, 1 << 30},
                                  {"rollout_packed", &ses_handle::tune_rollout_packed, -1, 1},
+                                 {"rollout_mix_8_16", &ses_handle::tune_rollout_mix_8_16, 0, 1},
                                  {"lander_offspring_per_wave", &ses_handle::tune_lander_per_wave, 0, 4},
                                  {"box2d_lanes_per_env", &ses_handle::tune_box2d_lpe, 0, 64},
                                  {"box2d_envs_per_wave", &ses_handle::tune_box2d_epw, 0, 64},

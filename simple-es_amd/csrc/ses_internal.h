@@ -29,12 +29,14 @@ struct ses_handle {
     // kernel-selection thresholds (ses_set_tuning; the defaults are the measured crossovers, ses_rollout.hip)
     int tune_rollout_block;        // workgroup size of the pure-LPE CartPole MLP rollout: 64 or 256
     int tune_gru_mfma_min_e;       // eval_ep_num from which GRU rollouts run on the MFMA kernel
+    int tune_gru_mfma4_min_e;      // eval_ep_num (... 8) from which the CartPole GRU rollout takes the 4x4x1 MFMA step; 0 = never
     int tune_gru_ep_parallel_max;  // (offspring x episode) count up to which GRU rollouts use one wave per episode
     int tune_gru_sequential;       // 1: episode-after-episode GRU kernels only
     int tune_rollout_mix;          // 0: no mixed LPE-8 / LPE-4 split for mid-sized CartPole MLP populations
     int tune_rollout_waves8;       // light waves of the mixed split
     int tune_rollout_mix_light;    // lanes per env of the light waves: 0 = choose, 8, 16
     int tune_rollout_lpe32_max;    // CartPole MLP populations of up to this many envs run at 32 lanes per env (0: never)
+    int tune_rollout_mix_8_16;     // 1: the (8 lanes per env on every SIMD + the rest at 16) split is a candidate (round 6)
     int tune_rollout_packed;       // the packed step of lone waves (ses_policy_pk.h): -1 = when every wave has a SIMD to itself, 0 / 1
     // ses_set_stamp: where the next stamped launch of this handle writes the GPU real-time counter (or null)
     unsigned long long *stamp;

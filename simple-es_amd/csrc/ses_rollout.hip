@@ -7,6 +7,7 @@
 #include "ses_gru.h"
 #include "ses_gru_lockstep.h"
 #include "ses_gru_mfma.h"
+#include "ses_gru_mfma4.h"
 #include "ses_lander.h"
 #include "ses_walker.h"
 #include "ses_internal.h"
@@ -212,7 +213,11 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_cartpole_mlp(const float *__r
 // benchmark population -- 20 480 envs -- 1024 such waves + 1024 waves at 4 lanes per env put exactly one light and one
 // heavy wave, 20 envs and 243 instructions per step on EVERY SIMD (LIGHT = 8: 264 on three quarters of them, a lone
 // light wave on the rest).  launch_cartpole_mlp picks the split whose busiest SIMD has the least to issue.
-template <bool FIXED_LENGTH, int LIGHT>
+// Round 6: the second kind of wave is a template argument too.  REST = 4: as above.  (FIRST, REST) = (8, 16): populations between
+// one and one and a half waves per SIMD at 8 lanes per env (8192 < envs <= 12 288: the 2048 offspring per GPU of the strong line at
+// two GPUs) -- 1024 waves of 8 envs, one per SIMD, then the remaining envs four to a wave: a doubled SIMD issues 104 + 83 instructions
+// per step where the pure split gave a quarter of the SIMDs 2 x 104.
+template <bool FIXED_LENGTH, int LIGHT, int REST = 4>
 __global__ __launch_bounds__(64) void k_rollout_cartpole_mlp_mix(const float *__restrict__ theta,
                                                                  const float *__restrict__ init,
                                                                  int init_per_offspring, int n_rows, int E, int P,
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(64) void k_rollout_cartpole_mlp_mix(const float *__
                                                                  double *__restrict__ ep_return,
                                                                  int32_t *__restrict__ ep_steps)
 {
-    constexpr int EPW = 64 / LIGHT;                    // envs of a light wave
+    constexpr int EPW = 64 / LIGHT;                    // envs of a wave of the first kind
     __shared__ TanhEntry tanh_tab[SES_TANH_N];
     stage_tanh_table(tanh_tab);
     const int n_env = n_rows * E;
@@ -229,9 +234,9 @@ __global__ __launch_bounds__(64) void k_rollout_cartpole_mlp_mix(const float *__
                                                        init_per_offspring, n_env < waves_light * EPW ? n_env : waves_light * EPW,
                                                        E, P, max_step, obs_mask, ep_return, ep_steps);
     } else {
-        rollout_cartpole_mlp_body<4, FIXED_LENGTH>(tanh_tab, (long long)(blockIdx.x - waves_light) * 64 + threadIdx.x,
-                                                   waves_light * EPW, theta, init, init_per_offspring, n_env, E, P, max_step,
-                                                   obs_mask, ep_return, ep_steps);
+        rollout_cartpole_mlp_body<REST, FIXED_LENGTH>(tanh_tab, (long long)(blockIdx.x - waves_light) * 64 + threadIdx.x,
+                                                      waves_light * EPW, theta, init, init_per_offspring, n_env, E, P, max_step,
+                                                      obs_mask, ep_return, ep_steps);
     }
 }
 
@@ -471,6 +476,86 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_rollout_gru_lockstep(const fl
             default: SES_LS_CASE(4, false); break;
         }
 #undef SES_LS_CASE
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The lockstep GRU rollout with the policy step on v_mfma_f32_4x4x1_16b_f32 (ses_gru_mfma4.h, round 6): one offspring per
+// wave, up to 8 episodes, lane l owns the env of episode (l & 7) exactly as in gru_lockstep_batch; only the policy differs.
+template <typename EnvT, bool FIXED_LENGTH>
+__device__ __forceinline__ void gru_mfma4_batch(const TanhEntry *tanh_tab, GruMfma4Lds<EnvT::S, EnvT::A> &lds,
+                                                const GruMfma4<EnvT::S, EnvT::A> &net, int lane, int nb,
+                                                const float *__restrict__ init_rows, int max_step, uint32_t obs_mask,
+                                                double *__restrict__ ret_out, int32_t *__restrict__ steps_out, bool valid_row)
+{
+    constexpr int S = EnvT::S, A = EnvT::A;
+    const int slot = lane & 7;
+    const bool owner_valid = slot < nb;
+    typename EnvT::State st;
+    EnvT::reset(st, init_rows + (size_t)(owner_valid ? slot : 0) * EnvT::INIT_W, slot);   // padding slots replay episode 0
+    float hreg[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                     // GymEnvModel.reset()
+    wave_lds_sync();
+    if (lane < 32) {
+#pragma unroll
+        for (int e = 0; e < G4_EB; ++e) lds.ah[e][lane][1] = 0.0f;
+    }
+    double ret = 0.0;
+    int steps = 0;
+    bool alive = true;
+    for (int t = 0; t < max_step; ++t) {
+        if constexpr (!FIXED_LENGTH) {
+            if (__ballot(alive & owner_valid) == 0ull) break;
+        }
+        float obs[S];
+        EnvT::observe(st, obs);
+        if (lane < G4_EB) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) lds.obs[lane][k] = ((obs_mask >> k) & 1u) ? 0.0f : obs[k];
+        }
+        wave_lds_sync();
+        net.step(tanh_tab, lds, hreg, lane);
+        float logits[A];
+        GruMfma4<S, A>::logits_of(lds, lane, logits);
+        bool term;
+        const bool freeze = FIXED_LENGTH ? false : !alive;
+        const float r = EnvT::step(st, logits, tanh_tab, freeze, term);
+        const int nsteps = steps + 1;
+        const bool finished = term | (nsteps >= max_step);
+        ret = alive ? ret + (double)r : ret;
+        steps = alive ? nsteps : steps;
+        alive = alive & !finished;
+    }
+    if (valid_row && lane < G4_EB && owner_valid) {
+        if (ret_out) ret_out[slot] = ret;
+        if (steps_out) steps_out[slot] = steps;
+    }
+}
+
+// 4 offspring per 256-thread workgroup (one copy of the tanh table), ONE wave per SIMD: the lane's 192 gate weights, the 12
+// accumulators of the interleaved chains and the operands of the k-pairs in flight want the whole register file.
+template <typename EnvT, bool FIXED_LENGTH>
+__global__ __launch_bounds__(256, 1) void k_rollout_gru_mfma4(const float *__restrict__ theta, const float *__restrict__ init,
+                                                              int init_per_offspring, int n_rows, int E, int P, int max_step,
+                                                              uint32_t obs_mask, double *__restrict__ ep_return,
+                                                              int32_t *__restrict__ ep_steps)
+{
+    __shared__ TanhEntry tanh_tab[SES_TANH_N];
+    __shared__ __attribute__((aligned(16))) GruMfma4Lds<EnvT::S, EnvT::A> ldsv[4];
+    stage_tanh_table(tanh_tab);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int row = blockIdx.x * 4 + wave;
+    const bool valid = row < n_rows;
+    row = valid ? row : n_rows - 1;
+    GruMfma4Lds<EnvT::S, EnvT::A> &lds = ldsv[wave];
+    GruMfma4<EnvT::S, EnvT::A> net;
+    net.load(theta + (size_t)row * P, lane, lds);
+    wave_lds_sync();
+    for (int e0 = 0; e0 < E; e0 += G4_EB) {
+        const int nb = E - e0 < G4_EB ? E - e0 : G4_EB;
+        const float *rows = init + ((size_t)(init_per_offspring ? row : 0) * E + e0) * EnvT::INIT_W;
+        double *ro = ep_return ? ep_return + (size_t)row * E + e0 : nullptr;
+        int32_t *so = ep_steps ? ep_steps + (size_t)row * E + e0 : nullptr;
+        gru_mfma4_batch<EnvT, FIXED_LENGTH>(tanh_tab, lds, net, lane, nb, rows, max_step, obs_mask, ro, so, valid);
     }
 }
 
@@ -1194,6 +1279,12 @@ static void launch_box2d_mlp(ses_handle *h, const float *theta, const float *ini
 
 static int gru_mfma_min_e(const ses_handle *h) { return h->tune_gru_mfma_min_e; }
 
+// eval_ep_num for which the CartPole GRU rollout takes the 4x4x1 MFMA step (ses_set_tuning "gru_mfma4_min_e" ... 8; 0 = never)
+static bool gru_mfma4(const ses_handle *h)
+{
+    return h->tune_gru_mfma4_min_e > 0 && h->cfg.eval_ep_num >= h->tune_gru_mfma4_min_e && h->cfg.eval_ep_num <= G4_EB;
+}
+
 // Small populations: the chip is far from full and what a rollout costs is the latency of max_step sequential env
 // steps.  The lockstep kernel spends ~1.7 us per step (all E episodes of an offspring in one wave), the
 // episode-after-episode kernel ~0.75 us per step and episode -- launched with one wave per (offspring, episode) it
@@ -1231,8 +1322,8 @@ static int lander_offspring_per_wave(const ses_handle *h, int n_rows)
 // (8 or 16 lanes per env) + the rest at 4 lanes per env".  Measured against the model at 3072 / 4096 / 5120 offspring x 5
 // episodes: pure 8 (167.7 us) / light 16 + 4 (195.0 us; round 2's light 8 + 4: 213.8) / pure 4 (239.5), all as predicted.
 struct MlpSplit {
-    int light;      // 0: pure split at `lpe` lanes per env; 8 / 16: mixed, light waves at this many lanes per env
-    int lpe;
+    int light;      // 0: pure split at `lpe` lanes per env; 8 / 16: mixed, the first waves at this many lanes per env
+    int lpe;        // pure: lanes per env; mixed: lanes per env of the remaining waves (4, or 16 behind first waves of 8)
 };
 
 static MlpSplit choose_cartpole_mlp_split(const ses_handle *h, long long episodes)
@@ -1242,7 +1333,7 @@ static MlpSplit choose_cartpole_mlp_split(const ses_handle *h, long long episode
     // off by default: profiles/r06_small_populations.txt has the A/B that decides it
     if (h->tune_rollout_lpe32_max > 0 && episodes <= h->tune_rollout_lpe32_max) return MlpSplit{0, 32};
     if (episodes > 49152) return MlpSplit{0, 4};                       // large populations: 4 lanes per env (round 1 sweep)
-    const int simds = h->tune_rollout_waves8;                           // 1024 = 256 CUs x 4 (knob: the light waves of a mix)
+    const int simds = h->tune_rollout_waves8;                           // 1024 = 256 CUs x 4 (knob: the first waves of a mix)
     auto instr = [](int lpe) { return lpe == 4 ? 160.0 : (lpe == 8 ? 104.0 : 84.0); };
     auto cadence = [](long long k) { return k <= 1 ? 5.0 : (k == 2 ? 3.45 : (k == 3 ? 3.1 : 2.95)); };
     MlpSplit best{0, 8};
@@ -1265,6 +1356,12 @@ static MlpSplit choose_cartpole_mlp_split(const ses_handle *h, long long episode
             const long long kh = ceil_div(ceil_div(episodes - envs_light, 16), simds);
             consider(MlpSplit{light, 4}, (instr(light) + 160.0 * kh) * cadence(1 + kh));
         }
+        // 8 lanes per env on every SIMD, the rest at 16 lanes per env (round 6; knob "rollout_mix_8_16", default on)
+        const long long envs8 = (long long)simds * 8;
+        if (h->tune_rollout_mix_8_16 && !mix_only && episodes > envs8) {
+            const long long k16 = ceil_div(ceil_div(episodes - envs8, 4), simds);
+            consider(MlpSplit{8, 16}, (104.0 + 84.0 * k16) * cadence(1 + k16));
+        }
     }
     return best;
 }
@@ -1275,18 +1372,22 @@ static void launch_cartpole_mlp(const ses_handle *h, const float *theta, const f
     const long long episodes = (long long)n_rows * h->cfg.eval_ep_num;
     const MlpSplit sp = choose_cartpole_mlp_split(h, episodes);
     if (sp.light) {
-        // one light wave per SIMD (the dispatcher deals the first workgroups one per SIMD) + the rest at 4 lanes per env
-        const int epw = 64 / sp.light, knob = h->tune_rollout_waves8;
+        // one wave of the first kind per SIMD (the dispatcher deals the first workgroups one per SIMD) + the rest
+        const int epw = 64 / sp.light, knob = h->tune_rollout_waves8, epw_rest = 64 / sp.lpe;
         const int waves_light = (long long)knob * epw < episodes ? knob : (int)(episodes / epw);
-        const int waves4 = ceil_div(episodes - (long long)epw * waves_light, 16);
-        const dim3 grid(waves_light + waves4), block(64);
-#define SES_MIX_LAUNCH(FIXED_, LIGHT_)                                                                                   \
-    hipLaunchKernelGGL((k_rollout_cartpole_mlp_mix<FIXED_, LIGHT_>), grid, block, 0, h->stream, theta, init, per, n_rows,   \
-                       h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, waves_light, epr, ep_steps)
+        const int waves_rest = ceil_div(episodes - (long long)epw * waves_light, epw_rest);
+        const dim3 grid(waves_light + waves_rest), block(64);
+#define SES_MIX_LAUNCH(FIXED_, LIGHT_, REST_)                                                                            \
+    hipLaunchKernelGGL((k_rollout_cartpole_mlp_mix<FIXED_, LIGHT_, REST_>), grid, block, 0, h->stream, theta, init, per,   \
+                       n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, waves_light, epr, ep_steps)
         if (mode == SES_MODE_FIXED_LENGTH) {
-            if (sp.light == 16) SES_MIX_LAUNCH(true, 16); else SES_MIX_LAUNCH(true, 8);
+            if (sp.lpe == 16) SES_MIX_LAUNCH(true, 8, 16);
+            else if (sp.light == 16) SES_MIX_LAUNCH(true, 16, 4);
+            else SES_MIX_LAUNCH(true, 8, 4);
         } else {
-            if (sp.light == 16) SES_MIX_LAUNCH(false, 16); else SES_MIX_LAUNCH(false, 8);
+            if (sp.lpe == 16) SES_MIX_LAUNCH(false, 8, 16);
+            else if (sp.light == 16) SES_MIX_LAUNCH(false, 16, 4);
+            else SES_MIX_LAUNCH(false, 8, 4);
         }
 #undef SES_MIX_LAUNCH
         return;
@@ -1456,6 +1557,15 @@ int ses_rollout(ses_handle *h, const float *theta, const float *init, int32_t in
             hipLaunchKernelGGL((k_rollout_cartpole_gru<false>), dim3(blocks), dim3(256), 0, h->stream, theta, init,
                                init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask,
                                epr, ep_steps, 1);
+    } else if (h->cfg.gru && !gru_sequential(h) && gru_mfma4(h)) {
+        // 4x4x1 MFMA blocks (ses_gru_mfma4.h): the policy step costs the same for any eval_ep_num up to 8
+        const int blocks = ceil_div(n_rows, 4);
+        if (mode == SES_MODE_FIXED_LENGTH)
+            hipLaunchKernelGGL((k_rollout_gru_mfma4<CartPoleLs, true>), dim3(blocks), dim3(256), 0, h->stream, theta, init,
+                               init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, epr, ep_steps);
+        else
+            hipLaunchKernelGGL((k_rollout_gru_mfma4<CartPoleLs, false>), dim3(blocks), dim3(256), 0, h->stream, theta, init,
+                               init_per_offspring, n_rows, h->cfg.eval_ep_num, h->P, h->cfg.max_step, h->obs_mask, epr, ep_steps);
     } else if (h->cfg.gru && !gru_sequential(h) && h->cfg.eval_ep_num >= gru_mfma_min_e(h)) {
         const int blocks = ceil_div(n_rows, 4);
         if (mode == SES_MODE_FIXED_LENGTH)

@@ -139,10 +139,11 @@ def test_lander_gru_rollout_on_the_matrix_cores_bit_exact():
 
 @pytest.mark.parametrize("knobs", [{"SES_TUNING": "gru_ep_parallel_max=0"},
                                    {"SES_TUNING": "gru_ep_parallel_max=0,gru_mfma_min_e=1"},
+                                   {"SES_TUNING": "gru_ep_parallel_max=0,gru_mfma4_min_e=1"},
                                    {"SES_TUNING": "gru_ep_parallel_max=1000000"},
                                    {"SES_TUNING": "gru_ep_parallel_max=0,lander_offspring_per_wave=2"},
                                    {"SES_TUNING": "gru_ep_parallel_max=0,lander_offspring_per_wave=4"}],
-                         ids=["lockstep", "mfma", "episode_parallel", "lander_2_per_wave", "lander_4_per_wave"])
+                         ids=["lockstep", "mfma", "mfma_4x4x1", "episode_parallel", "lander_2_per_wave", "lander_4_per_wave"])
 def test_gru_parity_suites_on_every_kernel_path(knobs):
     """ses_rollout picks the GRU kernel from the population size and episode count: one wave per (offspring, episode)
     up to 4096 episodes, the VALU lockstep kernel above, the MFMA kernel from 12 episodes.  The fixtures and most
@@ -154,6 +155,28 @@ def test_gru_parity_suites_on_every_kernel_path(knobs):
                           os.path.join(here, "test_gpu_lander.py"), "-k", "not every_kernel_path", "-m", "gpu"],
                          capture_output=True, text=True, env=env, timeout=1500, cwd=os.path.dirname(here))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("E", [1, 3, 4, 5, 6, 8])
+def test_gru_rollout_on_4x4x1_mfma_blocks_bit_exact(E):
+    """The CartPole GRU rollout with the policy step on v_mfma_f32_4x4x1_16b_f32 (ses_gru_mfma4.h; knob gru_mfma4_min_e): up to 8
+    episodes as two column blocks of four, one k per instruction -- the canonical chains bit for bit, so returns equal the C
+    oracle's in both modes, masked and unmasked, for full and ragged column blocks."""
+    from ses import HipES
+    rng = np.random.RandomState(40 + E)
+    n = 4200 // E + 1                                            # past the episode-parallel small-population path
+    theta = (rng.randn(n, 6562) * 0.4).astype(np.float32)
+    init = rng.uniform(-0.05, 0.05, (n, E, 4)).astype(np.float32)
+    for pomdp, mask in ((True, 0b1010), (False, 0)):
+        es = HipES("CartPole-v1", 4, 2, True, True, pomdp=pomdp, max_step=120, eval_ep_num=E)
+        es.set_tuning("gru_mfma4_min_e", 1)
+        o_fit, _, o_steps = co.rollout_cartpole(theta, init, E, 120, gru=True, obs_mask=mask)
+        for mode in (0, 1):
+            fit, _, ep_steps = es.rollout(dev(theta), dev(init), mode=mode, want_episodes=True)
+            assert np.array_equal(ep_steps.cpu().numpy(), o_steps), (E, pomdp, mode)
+            assert np.array_equal(bits(fit.cpu().numpy()), bits(o_fit))
+        es.close()
+    assert o_steps.max() > 50
 
 
 @pytest.mark.parametrize("E", [1, 2, 3, 8, 9, 11])

@@ -324,6 +324,28 @@ def test_rollout_per_offspring_init_and_pomdp(es):
     hp.close()
 
 
+@pytest.mark.parametrize("n", [2048, 1700, 2457, 3000, 4096])
+def test_rollout_mixed_splits_equal_the_oracle(n):
+    """Populations between one and a few waves per SIMD run MIXED splits of the lanes: 8 lanes per env on every SIMD + the rest at
+    16 (2048 offspring x 5 episodes, round 6), 16 lanes + the rest at 4 (the headline's 4096 x 5).  Every split -- the library's
+    choice, the (8, 16) mix switched off, the mixes switched off altogether -- is the same canonical arithmetic: bit-equal to the
+    oracle in both modes, ragged last waves included (1700 x 5 = 8500 envs: 77 waves of the second kind, the last one a quarter full)."""
+    from ses import HipES
+    rng = np.random.RandomState(n)
+    theta = (rng.randn(n, 226) * 0.6).astype(np.float32)
+    init = rng.uniform(-0.05, 0.05, (n, 5, 4)).astype(np.float32)
+    o_fit, _, o_steps = co.rollout_cartpole(theta, init, 5, 40)
+    for knobs in ({}, {"rollout_mix_8_16": 0}, {"rollout_mix": 0}):
+        h = HipES("CartPole-v1", 4, 2, True, False, max_step=40, eval_ep_num=5)
+        for name, value in knobs.items():
+            h.set_tuning(name, value)
+        for mode in (0, 1):
+            fit, _, ep_steps = h.rollout(dev(theta), dev(init), mode=mode, want_episodes=True)
+            assert np.array_equal(host(ep_steps), o_steps), (knobs, mode)
+            assert_bit_equal(host(fit), o_fit, f"{knobs} mode={mode}")
+        h.close()
+
+
 @pytest.mark.parametrize("lpe", [0, 4, 8, 16, 32])
 def test_rollout_wild_initial_states_take_the_general_loop(lpe):
     """Initial pole angles outside |th| <= 0.78 (not a reset the env produces, but the ABI accepts any state):
