@@ -613,7 +613,7 @@ def rank0_legs(args, result, timer, job, es, world, E, T, skip):
     timer.end()
     # ---- the per-GPU populations of the strong line (4096 offspring in total over 2 / 4 / 8 GPUs): ses_rollout alone, and what the
     # line of record is expected to read at N GPUs from these parts
-    if not args.no_extras and not args.gru and "small_shards" not in skip and E == 5 and T == 500:
+    if not args.no_extras and not args.gru and "small_shards" not in skip and E == 5 and T == 500 and world == 1:
         timer.begin("small_shards")
         try:
             small = {}
