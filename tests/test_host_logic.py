@@ -248,3 +248,42 @@ def test_spread_collision_threshold_is_where_the_root_reaches_the_contact_distan
     s = (t.view(np.uint32) + np.arange(-65536, 65536, dtype=np.int64)).astype(np.uint32).view(np.float32)
     r = np.sqrt(s)
     assert np.all(np.diff(r) >= 0) and np.array_equal(r < d, s < t)
+
+
+def test_bench_timing_helpers_on_the_cpu():
+    """bench.py's host-side bookkeeping (no GPU): the timed blocks repeat EXACTLY `steps` generations per block until they cover
+    --min-timed-seconds (never fewer than --blocks), the summary is the median block, the leg timers add up wall seconds."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench_helpers", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class FakeJob:
+        n_global, world, E, T = 4096, 1, 5, 500
+        calls = []
+
+        def generations(self, k):
+            self.calls.append(k)
+            time.sleep(0.004)
+
+        def steps_per_generation(self):
+            return self.n_global * self.E * self.T
+
+    job = FakeJob()
+    times = bench.timed_blocks(job, 7, 3, lambda: None, None, 1, min_seconds=0.05)
+    assert len(times) >= 3 and sum(times) >= 0.05 and set(job.calls) == {7} and len(job.calls) == len(times)
+    few = bench.timed_blocks(job, 7, 3, lambda: None, None, 1)               # no minimum: exactly --blocks blocks
+    assert len(few) == 3
+    rec = bench.summarise(job, 7, times)
+    assert rec["blocks"] == len(times) and rec["steps"] == 7 and rec["offspring_total"] == 4096
+    assert abs(rec["value"] - job.steps_per_generation() / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
+    assert rec["ms_per_step_min"] <= rec["ms_per_step"] <= rec["ms_per_step_max"] and abs(rec["timed_seconds"] - sum(times)) < 1e-9
+    legs = bench.Legs()
+    with legs.leg("a", gpu=False):
+        time.sleep(0.01)
+    legs.begin("b", gpu=False)
+    legs.end()
+    with legs.leg("a", gpu=False):
+        pass
+    assert legs.wall["a"] >= 0.01 and "b" in legs.wall and legs.gpu == {}
