@@ -19,6 +19,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include "ses_gru.h"
 
 namespace ses {
@@ -39,10 +41,14 @@ struct alignas(16) GruMfma4Lds {
     float y[G4_EB][36];           // tanh(h') for fc2 (144-B rows, as in the lockstep form)
     float obs[G4_EB][8];          // masked observations (S <= 8)
     float w2[A][32];
-    float b2[A];
-    float bi[96], bh[96];         // gate biases, row = 32 gate + unit
+    float bi[96], bh[96];         // gate biases, row = 32 gate + unit (read as float4 accumulator fragments: 16-byte aligned)
     float b1[32];
+    float b2[A];                  // last: its 4 A bytes must not push a float4-read array off its alignment
 };
+typedef GruMfma4Lds<4, 2> G4LdsCartPole;
+static_assert(offsetof(G4LdsCartPole, bi) % 16 == 0 && offsetof(G4LdsCartPole, bh) % 16 == 0 && offsetof(G4LdsCartPole, b1) % 16 == 0 &&
+                  offsetof(G4LdsCartPole, obs) % 16 == 0 && offsetof(G4LdsCartPole, y) % 16 == 0 && sizeof(G4LdsCartPole) % 16 == 0,
+              "every array that is read with ds_read_b128 stays 16-byte aligned in every wave's copy");
 
 template <int S, int A>
 struct GruMfma4 {
