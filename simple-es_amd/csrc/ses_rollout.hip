@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void k_rollout_cartpole_gru(const float *__res
         CartPoleState st{s0[0], s0[1], s0[2], s0[3]};
         float h = 0.0f;                                   // GymEnvModel.reset(), neural_network.py:38-40
         wave_lds_sync();
-        if (lane < 32) vec[32 + lane] = 0.0f;
+        if (lane < 32) vec[2 * lane + 1] = 0.0f;
         wave_lds_sync();
         int steps = 0;
         bool alive = true;
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256, 2) void k_rollout_lander_gru(const float *__re
             ll_reset(st, init + ((size_t)(init_per_offspring ? row : 0) * E + ep) * 16, terrain[wave]);
             float h = 0.0f;
             wave_lds_sync();
-            if (lane < 32) vec[32 + lane] = 0.0f;
+            if (lane < 32) vec[2 * lane + 1] = 0.0f;
             wave_lds_sync();
             double ret = 0.0;
             int steps = 0;
@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(256) void k_policy_forward_gru(const float *__restr
 #pragma unroll
     for (int k = 0; k < S; ++k) obs[k] = obs_in[(size_t)i * S + k];
     float h = hidden[(size_t)i * H + (lane & 31)];
-    if (lane < 32) vec[32 + lane] = h;
+    if (lane < 32) vec[2 * lane + 1] = h;
     wave_lds_sync();
     float logits[A];
     net.forward(tanh_tab, obs, h, vec, lane, logits);
