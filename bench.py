@@ -43,7 +43,6 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: both m
 
 import argparse
 import contextlib
-import hashlib
 import json
 import os
 import signal

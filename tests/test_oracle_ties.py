@@ -121,7 +121,7 @@ def test_the_default_sort_of_this_machine_is_reported_not_asserted(g4t, capsys):
 
 
 def test_bench_parity_note_quotes_the_tie_figures(g4t):
-    import importlib.util, sys
+    import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_for_ties", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
