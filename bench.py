@@ -983,8 +983,8 @@ def run_rank(args):
                 owner.set_tuning("comm_force_rccl", 0)
         return collective_leg(body)
 
-    with legs.leg("headline_rccl"):
-        result["strong_4096_total_rccl"] = rccl_twin(job, min(args.steps, 100), 7)
+    # (the RCCL-forced twins of the three jobs run LAST, behind a watchdog: see "the RCCL legs" below)
+    twins = [("strong_4096_total_rccl", job, min(args.steps, 100), 7)]
 
     # ---- the two other readings of the metric ------------------------------------------------------------------------
     if not args.no_extras:
@@ -1014,9 +1014,7 @@ def run_rank(args):
                 got = collective_leg(extra_job)                          # the headline line must still be printed
             if isinstance(got, tuple):
                 result[key], j = got
-                with legs.leg(key + "_rccl"):
-                    result[key + "_rccl"] = rccl_twin(j, x_steps, x_blocks)
-                del j
+                twins.append((key + "_rccl", j, x_steps, x_blocks))
             else:
                 result[key] = got
 
@@ -1069,9 +1067,54 @@ def run_rank(args):
             else:
                 result.update(rec)
 
+    es = job.loop.dev
+    if rank == 0:
+        rank0_legs(args, result, legs, job, es, world, E, T, skip)
+
+    def finish(note=None):
+        """Rank 0: complete the accounting and write THE line."""
+        if rank != 0:
+            return
+        for key_, _j, _s, _b in twins:
+            result.setdefault(key_, "absent" if world == 1 else "not run")
+        if note:
+            result["rccl_legs"] = note
+        result["legs_wall_s"] = {k: round(v, 3) for k, v in legs.wall.items()}
+        result["legs_gpu_event_s"] = {k: round(v, 3) for k, v in legs.gpu.items()}
+        result["gpu_event_seconds"] = round(sum(legs.gpu.values()), 3)
+        result["wall_seconds"] = round(time.perf_counter() - t_start, 3)
+        result["legs_note"] = ("wall seconds of rank 0 per leg; legs_gpu_event_s: the span between a HIP event recorded on the launch "
+                               "stream at the start of the leg and one at its end (the GPU side of the same leg, idle gaps while the host "
+                               "builds loops included); gpu_event_seconds their sum.  At n_gpus = 1 the CPU baseline runs first, before "
+                               "the HIP context exists: GPU activity starts after legs_wall_s.cpu_baseline seconds")
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(dict(result)) + "\n").encode())
+
     if world > 1:
+        # ---- the RCCL legs, LAST and behind a watchdog.  Everything above ran on the default transport (peer stores inside a node),
+        # whose exchanges give up after a time-out of their own.  An ncclAllGather whose peer never arrives waits for ever, and a
+        # multi-rank RCCL communicator is exactly what no box has run for this library yet: if these legs are not through within
+        # SES_BENCH_RCCL_BUDGET_S (150 s), every rank's watchdog ends its process with exit code 0 -- rank 0 after writing the line
+        # with what was measured and `"rccl_legs": "timed out ..."` -- instead of losing the run to the caller's limit.
+        import threading
+        dist.barrier()
+        budget = float(os.environ.get("SES_BENCH_RCCL_BUDGET_S", "150"))
+        through = threading.Event()
+
+        def watchdog():
+            if through.wait(budget):
+                return
+            note = (f"timed out after {budget:.0f} s in leg {getattr(legs, 'current', '?')}: everything measured before it is on the "
+                    "line, the RCCL twins / the RCCL column of allgather_microbench are not (complete)")
+            try:
+                try:
+                    finish(note)
+                except RuntimeError:                                   # the stuck main thread touched `result` meanwhile: once more
+                    finish(note)
+            finally:
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
         # ---- the exchange alone, both transports, every rank in step: 16 KB and 128 KB per rank ------------------------
-        # (before the rank-0-only legs below, during which the peers have nothing to do)
         def micro_leg():
             owner = getattr(job.loop.dev, "_comm_owner", None)
             micro = {}
@@ -1114,26 +1157,22 @@ def run_rank(args):
             return dict(micro, ranks=world, transports={"p2p_store": "attached" if have_p2p else "absent",
                                                         "rccl": "attached" if have_rccl else "absent"},
                         note="100 back-to-back ses_allgather_fitness per transport, max over ranks, us per exchange")
+        legs.current = "allgather_microbench"
         with legs.leg("allgather_microbench"):
             result["allgather_microbench"] = collective_leg(micro_leg)
-
-    es = job.loop.dev
-    if rank == 0:
-        rank0_legs(args, result, legs, job, es, world, E, T, skip)
-    if world > 1:
+        for key_, j_, steps_, blocks_ in twins:
+            if key_.split("_rccl")[0] in skip:
+                continue
+            legs.current = key_
+            with legs.leg(key_):
+                result[key_] = rccl_twin(j_, steps_, blocks_)
+        if os.environ.get("SES_BENCH_FAULT") == "rccl_hang":       # TEST HOOK: a leg that never returns (tests/test_gpu_multirank.py)
+            legs.current = "fault_injected_hang"
+            time.sleep(10 ** 6)
+        through.set()
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        result["legs_wall_s"] = {k: round(v, 3) for k, v in legs.wall.items()}
-        result["legs_gpu_event_s"] = {k: round(v, 3) for k, v in legs.gpu.items()}
-        result["gpu_event_seconds"] = round(sum(legs.gpu.values()), 3)
-        result["wall_seconds"] = round(time.perf_counter() - t_start, 3)
-        result["legs_note"] = ("wall seconds of rank 0 per leg; legs_gpu_event_s: the span between a HIP event recorded on the launch "
-                               "stream at the start of the leg and one at its end (the GPU side of the same leg, idle gaps while the host "
-                               "builds loops included); gpu_event_seconds their sum.  At n_gpus = 1 the CPU baseline runs first, before "
-                               "the HIP context exists: GPU activity starts after legs_wall_s.cpu_baseline seconds")
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    finish()
     return 0
 
 

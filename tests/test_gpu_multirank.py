@@ -536,3 +536,14 @@ def test_bench_shard_check_catches_a_wrong_shard(tmp_path):
     chk = line["strong_4096_total"]["shard_check"]
     assert chk["fitness_bit_equal"] is False and chk["bit_equal"] is False, chk
     assert chk["state_bit_equal"] is True, chk                        # the fault touched the checked exchange only
+
+
+def test_bench_survives_a_hanging_rccl_leg(tmp_path):
+    """The RCCL-forced twins run last and behind a watchdog: a leg that never returns (SES_BENCH_FAULT=rccl_hang stands in for an
+    ncclAllGather whose peer never arrives) costs the run its RCCL legs, not its line -- every rank exits with code 0 after
+    SES_BENCH_RCCL_BUDGET_S, rank 0 having written the line with everything measured before."""
+    line = _bench_line(2, {"SES_BENCH_FAULT": "rccl_hang", "SES_BENCH_RCCL_BUDGET_S": "8",
+                           "SES_BENCH_SKIP": "c3 loop e1 weak_4096_per_gpu c4_65536_total small_shards"}, tmp_path)
+    assert line["rccl_legs"].startswith("timed out after 8 s in leg fault_injected_hang"), line.get("rccl_legs")
+    assert line["strong_4096_total"]["shard_check"]["bit_equal"] is True
+    assert line["strong_4096_total_rccl"] == "absent" and line["value"] > 0 and "legs_wall_s" in line
