@@ -35,7 +35,9 @@ Box2D MLP configs (N = 1); `small_shards` -- the rollout at the per-GPU populati
 At N > 1 every job carries a `shard_check` (the run certifies itself on the box it is timed on): one generation's all-gathered
 fitness vector against rank 0's OWN rollout of the whole population, and the parent / Adam moments after a few generations of the
 timed path against rank 0's own single-rank replay from the same snapshot -- `bit_equal` must be true on every rank; each `*_rccl`
-twin asserts that its communicator spans all N ranks.  `legs_wall_s` / `legs_gpu_event_s` say where the run's time went.
+twin asserts that its communicator spans all N ranks.  The RCCL-forced legs run LAST, behind a watchdog (SES_BENCH_RCCL_BUDGET_S):
+if they hang, the line is still written with everything measured on the default transport.  `legs_wall_s` / `legs_gpu_event_s` say
+where the run's time went.
 """
 import os
 
