@@ -77,3 +77,15 @@ def test_product_never_imports_the_oracle():
                         "oracle/ses_oracle.c", ""):
                     offenders.append(os.path.join(d, f))
     assert not offenders, offenders
+
+
+def test_every_tuning_knob_is_documented_in_the_header():
+    """ses_set_tuning's table (csrc/ses_core.hip) and the knob list in include/ses.h's comment must not drift apart: every knob the
+    library accepts is named in the header a caller reads."""
+    import re
+    core = open(os.path.join(ROOT, "simple-es_amd", "csrc", "ses_core.hip")).read()
+    header = open(os.path.join(ROOT, "include", "ses.h")).read()
+    knobs = re.findall(r'\{"([a-z0-9_]+)", &ses_handle::tune_', core)
+    assert len(knobs) >= 30 and len(set(knobs)) == len(knobs)
+    missing = [k for k in knobs if f'"{k}"' not in header]
+    assert not missing, f"knobs accepted by ses_set_tuning but absent from include/ses.h: {missing}"
