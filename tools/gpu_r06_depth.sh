@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, call C (evidence at depth, ~17 minutes): skip reasons of the real-device tests, a long fuzz pass, the soak runs
+# round 6 (evidence at depth, ~17 minutes): skip reasons of the real-device tests, a long fuzz pass, the soak runs
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, call E: every multi-rank GPU test six times in a row on one box (no retry anywhere), then the in-process rig twenty times
+# round 6: every multi-rank GPU test six times in a row on one box (no retry anywhere), then the in-process rig twenty times
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
