@@ -543,7 +543,7 @@ def rank0_legs(args, result, timer, job, es, world, E, T, skip):
                                         "reference's E = 5 it is at par with v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4x1 blocks, 5 of 8 columns "
                                         "used: 0.97-1.04 x its time, bit-identical sums) and 1.5 x faster than the 5/16-full 16x16x4 tile; the "
                                         "4x4x1 form wins the CONTRACTION from 6 episodes (1.74 x at 8) but loses as a KERNEL (k_rollout_gru_mfma4, bit-exact, knob "
-                                        "gru_mfma4_min_e: 4.01 ms against 2.42 ms at 5 episodes -- 192 resident weights per lane leave one wave "
+                                        "gru_mfma4_min_e: 4.01 ms against 2.39 ms at 5 episodes -- 192 resident weights per lane leave one wave "
                                         "per SIMD, profiles/r06_time_gru.txt); the 16x16x4 kernel runs from 12"}
     if args.gru and E >= 12:
         # the GRU rollout runs on v_mfma_f32_16x16x4_f32 from 12 episodes up: 2 fc1 + 96 gate + 8 fc2 tiles per
