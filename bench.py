@@ -35,8 +35,9 @@ Box2D MLP configs (N = 1); `small_shards` -- the rollout at the per-GPU populati
 At N > 1 every job carries a `shard_check` (the run certifies itself on the box it is timed on): one generation's all-gathered
 fitness vector against rank 0's OWN rollout of the whole population, and the parent / Adam moments after a few generations of the
 timed path against rank 0's own single-rank replay from the same snapshot -- `bit_equal` must be true on every rank; each `*_rccl`
-twin asserts that its communicator spans all N ranks.  The RCCL-forced legs run LAST, behind a watchdog (SES_BENCH_RCCL_BUDGET_S):
-if they hang, the line is still written with everything measured on the default transport.  `legs_wall_s` / `legs_gpu_event_s` say
+twin asserts that its communicator spans all N ranks.  The RCCL-forced legs run LAST, and a watchdog holds them to
+SES_BENCH_RCCL_BUDGET_S (150 s) and the whole multi-GPU run to SES_BENCH_TOTAL_BUDGET_S (420 s): if a collective hangs once the
+headline has been measured, the line is still written with everything measured so far (`"watchdog": ...`) and every rank exits 0.  `legs_wall_s` / `legs_gpu_event_s` say
 where the run's time went.
 """
 import os
@@ -385,7 +386,7 @@ class Legs:
     HIP event recorded on the launch stream when the leg starts and one when it ends."""
 
     def __init__(self):
-        self.wall, self.gpu, self._open = {}, {}, None
+        self.wall, self.gpu, self._open, self.current = {}, {}, None, "start-up"
 
     def begin(self, name, gpu=True):
         self._open = self.leg(name, gpu)
@@ -398,6 +399,7 @@ class Legs:
 
     @contextlib.contextmanager
     def leg(self, name, gpu=True):
+        self.current = name                                   # (what a watchdog names when a budget runs out)
         t0 = time.perf_counter()
         ev = None
         if gpu:
@@ -893,6 +895,56 @@ def run_rank(args):
             return {"error": err or "failed on another rank"}
         return rec if err is None else {"error": err}
 
+    def finish(note=None):
+        """Rank 0: complete the accounting and write THE line."""
+        if rank != 0:
+            return
+        for key_ in ("strong_4096_total_rccl", "weak_4096_per_gpu_rccl", "c4_65536_total_rccl"):
+            if key_ != "weak_4096_per_gpu_rccl" or world > 1:
+                result.setdefault(key_, "absent" if world == 1 else "not run")
+        if note:
+            result["watchdog"] = note
+        result["legs_wall_s"] = {k: round(v, 3) for k, v in legs.wall.items()}
+        result["legs_gpu_event_s"] = {k: round(v, 3) for k, v in legs.gpu.items()}
+        result["gpu_event_seconds"] = round(sum(legs.gpu.values()), 3)
+        result["wall_seconds"] = round(time.perf_counter() - t_start, 3)
+        result["legs_note"] = ("wall seconds of rank 0 per leg; legs_gpu_event_s: the span between a HIP event recorded on the launch "
+                               "stream at the start of the leg and one at its end (the GPU side of the same leg, idle gaps while the host "
+                               "builds loops included); gpu_event_seconds their sum.  At n_gpus = 1 the CPU baseline runs first, before "
+                               "the HIP context exists: GPU activity starts after legs_wall_s.cpu_baseline seconds")
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(dict(result)) + "\n").encode())
+
+    # ---- watchdog (n_gpus > 1).  A multi-GPU run meets things no box has run for this library -- peer stores across xGMI, an RCCL
+    # communicator with more than one rank -- and a collective whose peer never arrives waits for ever.  Two budgets: the whole run
+    # (SES_BENCH_TOTAL_BUDGET_S, 420 s) and, tighter, the RCCL-forced legs at its end (SES_BENCH_RCCL_BUDGET_S, 150 s).  When one
+    # expires every rank's watchdog ends its process: with exit code 0 if the headline has been measured -- rank 0 first writes the
+    # line with everything measured so far and `"watchdog": "..."` -- with exit code 4 (and a message on stderr) if not.
+    guard = {"deadline": None, "what": "", "through": None}
+    if world > 1:
+        import threading
+        guard["through"] = threading.Event()
+        guard["deadline"] = time.monotonic() + float(os.environ.get("SES_BENCH_TOTAL_BUDGET_S", "420"))
+        guard["what"] = "the run's budget (SES_BENCH_TOTAL_BUDGET_S)"
+
+        def watchdog():
+            while not guard["through"].wait(0.5):
+                if time.monotonic() < guard["deadline"]:
+                    continue
+                note = (f"{guard['what']} ran out in leg {getattr(legs, 'current', '?')}: everything measured before it is on the line, "
+                        "that leg and what follows it are not (complete)")
+                if "value" not in result:
+                    print(f"bench.py: rank {rank}: {note}; the headline had not been measured: no line", file=sys.stderr, flush=True)
+                    os._exit(4)
+                try:
+                    try:
+                        finish(note)
+                    except RuntimeError:                               # the stuck main thread touched `result` meanwhile: once more
+                        finish(note)
+                finally:
+                    os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+
     E, T = args.eval_ep_num, args.max_step
     work = tempfile.mkdtemp(prefix="ses_bench_")               # ESLoop writes logs/<env>/<stamp>/ under the cwd
     os.chdir(work)
@@ -1073,49 +1125,15 @@ def run_rank(args):
     if rank == 0:
         rank0_legs(args, result, legs, job, es, world, E, T, skip)
 
-    def finish(note=None):
-        """Rank 0: complete the accounting and write THE line."""
-        if rank != 0:
-            return
-        for key_, _j, _s, _b in twins:
-            result.setdefault(key_, "absent" if world == 1 else "not run")
-        if note:
-            result["rccl_legs"] = note
-        result["legs_wall_s"] = {k: round(v, 3) for k, v in legs.wall.items()}
-        result["legs_gpu_event_s"] = {k: round(v, 3) for k, v in legs.gpu.items()}
-        result["gpu_event_seconds"] = round(sum(legs.gpu.values()), 3)
-        result["wall_seconds"] = round(time.perf_counter() - t_start, 3)
-        result["legs_note"] = ("wall seconds of rank 0 per leg; legs_gpu_event_s: the span between a HIP event recorded on the launch "
-                               "stream at the start of the leg and one at its end (the GPU side of the same leg, idle gaps while the host "
-                               "builds loops included); gpu_event_seconds their sum.  At n_gpus = 1 the CPU baseline runs first, before "
-                               "the HIP context exists: GPU activity starts after legs_wall_s.cpu_baseline seconds")
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(dict(result)) + "\n").encode())
-
     if world > 1:
         # ---- the RCCL legs, LAST and behind a watchdog.  Everything above ran on the default transport (peer stores inside a node),
         # whose exchanges give up after a time-out of their own.  An ncclAllGather whose peer never arrives waits for ever, and a
-        # multi-rank RCCL communicator is exactly what no box has run for this library yet: if these legs are not through within
-        # SES_BENCH_RCCL_BUDGET_S (150 s), every rank's watchdog ends its process with exit code 0 -- rank 0 after writing the line
-        # with what was measured and `"rccl_legs": "timed out ..."` -- instead of losing the run to the caller's limit.
-        import threading
+        # multi-rank RCCL communicator is exactly what no box has run for this library yet: these legs get a budget of their own
+        # (the watchdog above), so that a hang here costs the RCCL columns and not the line.
         dist.barrier()
-        budget = float(os.environ.get("SES_BENCH_RCCL_BUDGET_S", "150"))
-        through = threading.Event()
-
-        def watchdog():
-            if through.wait(budget):
-                return
-            note = (f"timed out after {budget:.0f} s in leg {getattr(legs, 'current', '?')}: everything measured before it is on the "
-                    "line, the RCCL twins / the RCCL column of allgather_microbench are not (complete)")
-            try:
-                try:
-                    finish(note)
-                except RuntimeError:                                   # the stuck main thread touched `result` meanwhile: once more
-                    finish(note)
-            finally:
-                os._exit(0)
-        threading.Thread(target=watchdog, daemon=True).start()
+        rccl_budget = float(os.environ.get("SES_BENCH_RCCL_BUDGET_S", "150"))
+        guard["deadline"] = min(guard["deadline"], time.monotonic() + rccl_budget)
+        guard["what"] = f"the budget of the RCCL legs ({rccl_budget:.0f} s, SES_BENCH_RCCL_BUDGET_S)"
         # ---- the exchange alone, both transports, every rank in step: 16 KB and 128 KB per rank ------------------------
         def micro_leg():
             owner = getattr(job.loop.dev, "_comm_owner", None)
@@ -1171,7 +1189,7 @@ def run_rank(args):
         if os.environ.get("SES_BENCH_FAULT") == "rccl_hang":       # TEST HOOK: a leg that never returns (tests/test_gpu_multirank.py)
             legs.current = "fault_injected_hang"
             time.sleep(10 ** 6)
-        through.set()
+        guard["through"].set()
         dist.barrier()
         dist.destroy_process_group()
     finish()

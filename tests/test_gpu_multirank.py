@@ -541,9 +541,19 @@ def test_bench_shard_check_catches_a_wrong_shard(tmp_path):
 def test_bench_survives_a_hanging_rccl_leg(tmp_path):
     """The RCCL-forced twins run last and behind a watchdog: a leg that never returns (SES_BENCH_FAULT=rccl_hang stands in for an
     ncclAllGather whose peer never arrives) costs the run its RCCL legs, not its line -- every rank exits with code 0 after
-    SES_BENCH_RCCL_BUDGET_S, rank 0 having written the line with everything measured before."""
+    SES_BENCH_RCCL_BUDGET_S, rank 0 having written the line with everything measured before.  (The same watchdog holds the whole
+    multi-GPU run to SES_BENCH_TOTAL_BUDGET_S: a second case lets that one run out before the headline is measured -- exit code 4,
+    no line.)"""
     line = _bench_line(2, {"SES_BENCH_FAULT": "rccl_hang", "SES_BENCH_RCCL_BUDGET_S": "8",
                            "SES_BENCH_SKIP": "c3 loop e1 weak_4096_per_gpu c4_65536_total small_shards"}, tmp_path)
-    assert line["rccl_legs"].startswith("timed out after 8 s in leg fault_injected_hang"), line.get("rccl_legs")
+    assert "budget of the RCCL legs (8 s" in line["watchdog"] and "fault_injected_hang" in line["watchdog"], line.get("watchdog")
     assert line["strong_4096_total"]["shard_check"]["bit_equal"] is True
     assert line["strong_4096_total_rccl"] == "absent" and line["value"] > 0 and "legs_wall_s" in line
+
+
+def test_bench_whose_budget_runs_out_before_the_headline_says_so(tmp_path):
+    env = {**os.environ, "SES_BENCH_BACKEND": "gloo", "SES_BENCH_TOTAL_BUDGET_S": "0.5"}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-roofline"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert out.returncode != 0 and not out.stdout.strip(), (out.returncode, out.stdout[-500:])
+    assert "the headline had not been measured: no line" in out.stderr, out.stderr[-2000:]
