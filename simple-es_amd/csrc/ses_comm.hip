@@ -396,6 +396,22 @@ int ses_comm_p2p_attach_local(ses_handle *h, ses_handle *const *peers)
                         q->p2p->max_per_rank == p->max_per_rank,
                     "ses_comm_p2p_attach_local: peers[%d] has not exported a mailbox of the same shape as rank %d of %d", r, r, p->world);
     }
+    // handles of one process on DIFFERENT devices (a host that drives several GPUs from one process): this device needs peer
+    // access to the device that owns the mailbox before a kernel may store into it (the IPC route asks for it when it maps the
+    // handle, hipIpcMemLazyEnablePeerAccess; here the pointer is used as it is)
+    for (int r = 0; r < p->world; ++r) {
+        const int peer_dev = peers[r]->cfg.device;
+        if (peer_dev == h->cfg.device) continue;
+        SES_HIP_TRY(hipSetDevice(h->cfg.device));
+        int can = 0;
+        SES_HIP_TRY(hipDeviceCanAccessPeer(&can, h->cfg.device, peer_dev));
+        SES_REQUIRE(can, "ses_comm_p2p_attach_local: device %d cannot access the memory of device %d (rank %d's mailbox)",
+                    h->cfg.device, peer_dev, r);
+        const hipError_t e = hipDeviceEnablePeerAccess(peer_dev, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+            return set_error(SES_ERR_COMM, "ses_comm_p2p_attach_local: hipDeviceEnablePeerAccess(%d): %s", peer_dev, hipGetErrorString(e));
+        (void)hipGetLastError();
+    }
     for (int r = 0; r < p->world; ++r) p->peer[r] = peers[r]->p2p->own;
     p->attached = true;
     p->local = true;
