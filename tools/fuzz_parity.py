@@ -208,6 +208,7 @@ def main():
             pomdp, lpe, p64 = bool(rng.randint(0, 2)), int(rng.choice([0, 0, 1, 2, 4, 8, 16, 32])), bool(rng.rand() < 0.15)
             es = HipES("CartPole-v1", 4, 2, True, False, pomdp=pomdp, max_step=T, eval_ep_num=E, lanes_per_env=lpe, physics64=p64)
             es.set_tuning("rollout_packed", int(rng.choice([-1, 0, 1])))      # the packed step of lone waves: by rule, never, always
+            es.set_tuning("rollout_mix_8_16", int(rng.rand() < 0.7))          # the (8, 16) mixed split (8193 ... ~12 000 envs)
             theta = (rng.randn(n, 226) * sigma).astype(np.float32)
             init = rng.uniform(-0.05, 0.05, (E, 4) if shared else (n, E, 4)).astype(np.float32)
             if rng.rand() < 0.2:
@@ -227,6 +228,8 @@ def main():
                 es.set_tuning("gru_sequential", int(rng.rand() < 0.2))
                 if rng.rand() < 0.3:
                     es.set_tuning("gru_mfma_min_e", 1)
+                elif rng.rand() < 0.4:
+                    es.set_tuning("gru_mfma4_min_e", 1)                  # the 4x4x1 MFMA step (taken for E <= 8)
             theta = (rng.randn(n, 6562) * min(sigma, 1.0)).astype(np.float32)
             init = rng.uniform(-0.05, 0.05, (E, 4) if shared else (n, E, 4)).astype(np.float32)
             ref = co.rollout_cartpole(theta, init, E, T, gru=True, obs_mask=0b1010 if pomdp else 0)
