@@ -544,27 +544,35 @@ def rank0_legs(args, result, timer, job, es, world, E, T, skip):
                                         "is v_pk_fma_f32 (input and hidden side in one instruction) at the MFMA rate with no padding -- at the "
                                         "reference's E = 5 it is at par with v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4x1 blocks, 5 of 8 columns "
                                         "used: 0.97-1.04 x its time, bit-identical sums) and 1.5 x faster than the 5/16-full 16x16x4 tile; the "
-                                        "4x4x1 form wins the CONTRACTION from 6 episodes (1.74 x at 8) but loses as a KERNEL (k_rollout_gru_mfma4, bit-exact, knob "
-                                        "gru_mfma4_min_e: 4.01 ms against 2.39 ms at 5 episodes -- 192 resident weights per lane leave one wave "
-                                        "per SIMD, profiles/r06_time_gru.txt); the 16x16x4 kernel runs from 12"}
-    if args.gru and E >= 12:
-        # the GRU rollout runs on v_mfma_f32_16x16x4_f32 from 12 episodes up: 2 fc1 + 96 gate + 8 fc2 tiles per
-        # step and 16-episode batch, 2048 flop per tile instruction (padding columns included), fp32 MFMA peak
-        # 157.3 TFLOP/s (MI355X_MICROARCH.md, Matrix cores)
-        flops = 106 * 2048.0 * n_local * ((E + 15) // 16) * T
+                                        "4x4x1 form wins the CONTRACTION from 6 episodes (1.74 x at 8) and, as a KERNEL (k_rollout_gru_mfma4, bit-exact: W_hh in "
+                                        "registers, W_ih in LDS, two waves per SIMD), takes 3.05 ms for any E <= 8 against 2.45 / 2.70 / 3.27 / "
+                                        "3.52 ms of the VALU kernel at 5 / 6 / 7 / 8 episodes (profiles/r06_time_gru.txt): the GRU rollout "
+                                        "runs on it at 7 and 8 episodes, on the 16x16x4 kernel from 12"}
+    if args.gru and (E >= 12 or 7 <= E <= 8):
+        if E >= 12:
+            # the GRU rollout runs on v_mfma_f32_16x16x4_f32 from 12 episodes up: 2 fc1 + 96 gate + 8 fc2 tiles per
+            # step and 16-episode batch, 2048 flop per tile instruction (padding columns included), fp32 MFMA peak
+            # 157.3 TFLOP/s (MI355X_MICROARCH.md, Matrix cores)
+            flops = 106 * 2048.0 * n_local * ((E + 15) // 16) * T
+            form, suffix_m, frag_m = "v_mfma_f32_16x16x4_f32", "_sq_gru_mfma.json", "k_rollout_gru_mfma"
+        else:
+            # 7 and 8 episodes: v_mfma_f32_4x4x1_16b_f32 (csrc/ses_gru_mfma4.h): 192 gate + 4 fc1 instructions per step, 16 blocks x
+            # 4x4x1 x 2 = 512 flop each (padding columns included)
+            flops = 196 * 512.0 * n_local * T
+            form, suffix_m, frag_m = "v_mfma_f32_4x4x1_16b_f32", "_sq_gru_mfma4.json", "k_rollout_gru_mfma4"
         result["rollout_kernel"].update({"bound": "fp32 mfma + valu (serial)", "mfma_tflops": flops / (roll_ms * 1e-3) / 1e12,
                                          "mfma_peak_tflops": 157.3,
                                          "mfma_frac": flops / (roll_ms * 1e-3) / 157.3e12,
-                                         "mfma": "v_mfma_f32_16x16x4_f32"})
+                                         "mfma": form})
         # matrix-pipe busy fraction (rocprof's MfmaUtil) from the newest committed SQ profile of this kernel, attached
         # only while the kernel's machine code is the profiled one
         newest = None
         for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
-            if name.endswith("_sq_gru_mfma.json"):
+            if name.endswith(suffix_m):
                 newest = os.path.join(ROOT, "profiles", name)
         if newest:
             sqm = json.load(open(newest))
-            now = kernel_code_hash("k_rollout_gru_mfma")
+            now = kernel_code_hash(frag_m)
             pd_ = sqm.get("per_dispatch", {})
             if sqm.get("kernel_code_sha256") and now == sqm["kernel_code_sha256"] and pd_.get("GRBM_GUI_ACTIVE"):
                 # GRBM_GUI_ACTIVE is summed over the 8 XCDs, each with 128 SIMDs

@@ -88,7 +88,7 @@ int ses_destroy(ses_handle *h);
 int ses_sync(ses_handle *h);
 /* Development / test hook: which of the (result-identical) rollout kernels a handle picks.  Every kernel evaluates the
  * same canonical arithmetic, so no setting changes a result; the defaults are the measured crossovers.  Knobs:
- * "gru_ep_parallel_max" (default 4096), "gru_mfma_min_e" (12), "gru_mfma4_min_e" (0 = never | 1 ... 8: eval_ep_num from which -- up to 8 -- the CartPole GRU rollout takes its policy step on v_mfma_f32_4x4x1_16b_f32), "gru_sequential" (0), "rollout_mix" (1),
+ * "gru_ep_parallel_max" (default 4096), "gru_mfma_min_e" (12), "gru_mfma4_min_e" (7; 0 = never | 1 ... 8: eval_ep_num from which -- up to 8 -- the CartPole GRU rollout takes its policy step on v_mfma_f32_4x4x1_16b_f32), "gru_sequential" (0), "rollout_mix" (1),
  * "rollout_waves8" (1024: light waves of the mixed CartPole MLP split), "rollout_mix_light" (their lanes per env: 0 = choose | 8 | 16), "rollout_lpe32_max_envs" (0: CartPole MLP populations of up to this many envs run at 32 lanes per env), "rollout_mix_8_16" (default 1: populations of 8193 ... ~12 000 envs run 8 lanes per env on every SIMD and the rest at 16), "rollout_packed" (-1: populations of at most one wave per SIMD run the packed form of the CartPole MLP step | 0: never | 1: whenever 8 or 16 lanes share an env), "rollout_block" (64 | 256), "lander_offspring_per_wave" (0 = by population size | 1 | 2 | 4),
  * "box2d_lanes_per_env" (0 = by population size | 1 | 2 | ... | 64: lanes that share one env in the LunarLander / BipedalWalker MLP rollout),
  * "box2d_envs_per_wave" (0 = by population size | 1 ... 64 / lanes per env: different envs a wave of that rollout carries),

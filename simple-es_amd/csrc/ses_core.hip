@@ -116,6 +116,7 @@ int ses_create(const ses_config *cfg, void *stream, ses_handle **out)
     if (cfg->pomdp && cfg->env_id == SES_ENV_LUNARLANDER) h->obs_mask = 0x2Cu;  // obs[2,3,5]      (gym_wrapper.py:61-66)
     h->tune_rollout_block = 64;
     h->tune_gru_mfma_min_e = 12;
+    h->tune_gru_mfma4_min_e = 7;              // measured (profiles/r06_time_gru.txt): 3.05 ms for any E <= 8 against 3.27 / 3.52 ms of the VALU lockstep kernel at 7 / 8
     h->tune_gru_ep_parallel_max = 4096;
     h->tune_gru_sequential = 0;
     h->tune_rollout_mix = 1;

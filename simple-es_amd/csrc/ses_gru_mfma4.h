@@ -6,8 +6,8 @@
 // k-ascending fma chain, bit for bit (tools/mfma_vs_valu_gru.hip: 0 of 86 528 outputs differ from fmaf on the host).
 //
 // Lane roles (lane l): block b = l >> 2, i = l & 3; episode block cb = b & 1, unit block ub = b >> 1.
-//   A operand of the lane = row (4 ub + i) of a weight matrix at column k        (the lane's 3 gates x 2 sides x 32 k = 192
-//                                                                                 gate weights live in VGPRs for the rollout)
+//   A operand of the lane = row (4 ub + i) of a weight matrix at column k        (W_hh: 96 values per lane in VGPRs for the rollout;
+//                                                                                 W_ih: read from the wave's LDS block, four k per read)
 //   B operand             = activation k of episode e = 4 cb + i                 (k-pairs of (a_k, h_k) from LDS)
 //   D register r          = (unit 4 ub + r, episode e)
 // so a lane ends a step with the gate pre-activations of FOUR units of ONE episode: the three gates of a (unit, episode) and
@@ -15,7 +15,11 @@
 // Canonical sums as everywhere (ses_gru.h): gate row = (bias + chain k < 16) + (chain k >= 16), input and hidden side apart;
 // fc1 = bias-first chain over the S inputs (S MFMAs with C = b1); fc2 and the env as in the lockstep form.
 // Cost per step: 192 + S MFMAs of 8 cycles for ANY number of episodes up to 8 -- against 48 v_pk_fma_f32 per episode in the
-// VALU form (at par at 5 episodes, 1.74 x faster at 8 on the contraction: profiles/r06_mfma_vs_valu_gru.txt).
+// VALU form.  Measured, POMDP CartPole, 4096 offspring x 500 steps (profiles/r06_time_gru.txt): 3.05 ms for every E <= 8; the VALU
+// lockstep kernel takes 2.45 / 2.70 / 3.27 / 3.52 ms at 5 / 6 / 7 / 8 episodes -- ses_rollout takes this step from 7 (knob
+// "gru_mfma4_min_e").  History: with all 192 gate weights of a lane in registers (the two column blocks of an offspring need the same
+// A rows: 2 x duplication) the kernel needed 360 registers = ONE wave per SIMD and took 4.01 ms -- a lone wave runs the ~480 non-MFMA
+// instructions of a step with every stall exposed; W_ih moved to LDS: 250 VGPRs, two waves per SIMD, 3.05 ms.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -26,6 +30,7 @@
 namespace ses {
 
 constexpr int G4_EB = 8;          // episodes per batch = 2 column blocks of 4
+constexpr int G4_WROW = 36;       // floats per W_ih row in LDS
 constexpr int G4_AH = 34;         // (a, h) pairs per episode row: 32 + 2 of padding -> rows 272 B apart, the 8 rows' ds_read_b128 hit 8 bank groups
 
 typedef float g4_f32x4 __attribute__((ext_vector_type(4)));
@@ -43,10 +48,13 @@ struct alignas(16) GruMfma4Lds {
     float w2[A][32];
     float bi[96], bh[96];         // gate biases, row = 32 gate + unit (read as float4 accumulator fragments: 16-byte aligned)
     float b1[32];
+    float wih[96][G4_WROW];       // W_ih, row = 32 gate + unit, 36 floats per row (144 B: the rows a wave reads together -- 32 of them,
+                                  // four k at a time -- fall on different bank groups); W_hh stays in registers
     float b2[A];                  // last: its 4 A bytes must not push a float4-read array off its alignment
 };
 typedef GruMfma4Lds<4, 2> G4LdsCartPole;
 static_assert(offsetof(G4LdsCartPole, bi) % 16 == 0 && offsetof(G4LdsCartPole, bh) % 16 == 0 && offsetof(G4LdsCartPole, b1) % 16 == 0 &&
+                  offsetof(G4LdsCartPole, wih) % 16 == 0 &&
                   offsetof(G4LdsCartPole, obs) % 16 == 0 && offsetof(G4LdsCartPole, y) % 16 == 0 && sizeof(G4LdsCartPole) % 16 == 0,
               "every array that is read with ds_read_b128 stays 16-byte aligned in every wave's copy");
 
@@ -54,8 +62,7 @@ template <int S, int A>
 struct GruMfma4 {
     static_assert(S == 4 || S == 8, "observations arrive as one or two float4");
     float w1[S];                  // W1[4 ub + i][s]
-    float wih[3][32];             // W_ih[32 g + 4 ub + i][k]
-    float whh[3][32];
+    float whh[3][32];             // W_hh[32 g + 4 ub + i][k]: resident (W_ih is read from the wave's LDS block, see step())
 
     __device__ __forceinline__ void load(const float *__restrict__ theta, int lane, GruMfma4Lds<S, A> &lds)
     {
@@ -70,10 +77,8 @@ struct GruMfma4 {
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                wih[g][k] = pih[(g * H + row) * H + k];
-                whh[g][k] = phh[(g * H + row) * H + k];
-            }
+            for (int k = 0; k < 32; ++k) whh[g][k] = phh[(g * H + row) * H + k];
+        for (int q = lane; q < 96 * 32; q += 64) lds.wih[q >> 5][q & 31] = pih[q];      // coalesced: 3072 consecutive floats
         for (int q = lane; q < 96; q += 64) {
             lds.bi[q] = pbi[q];
             lds.bh[q] = pbh[q];
@@ -126,22 +131,32 @@ struct GruMfma4 {
             hu[g] = g4_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
         const float4 *row = reinterpret_cast<const float4 *>(&lds.ah[e][0][0]);     // (a_k, h_k, a_k+1, h_k+1) per read
+        const float4 *wrow[3];                                                      // this lane's W_ih rows, four k per read
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 lo = row[q], up = row[8 + q];                              // k = 2q, 2q + 1 and 16 + 2q, 17 + 2q
+        for (int g = 0; g < 3; ++g) wrow[g] = reinterpret_cast<const float4 *>(&lds.wih[32 * g + 4 * ub + i][0]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // k = 4 q .. 4 q + 3 (lower half) and 16 + 4 q .. 19 + 4 q (upper half)
+            const float4 lo0 = row[2 * q], lo1 = row[2 * q + 1], up0 = row[8 + 2 * q], up1 = row[9 + 2 * q];
+            const float xa_lo[4] = {lo0.x, lo0.z, lo1.x, lo1.z}, xh_lo[4] = {lo0.y, lo0.w, lo1.y, lo1.w};
+            const float xa_up[4] = {up0.x, up0.z, up1.x, up1.z}, xh_up[4] = {up0.y, up0.w, up1.y, up1.w};
+            float4 wl[3], wu[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                il[g] = mfma_4x4x1(wih[g][2 * q], lo.x, il[g]);
-                hl[g] = mfma_4x4x1(whh[g][2 * q], lo.y, hl[g]);
-                iu[g] = mfma_4x4x1(wih[g][16 + 2 * q], up.x, iu[g]);
-                hu[g] = mfma_4x4x1(whh[g][16 + 2 * q], up.y, hu[g]);
+                wl[g] = wrow[g][q];
+                wu[g] = wrow[g][4 + q];
             }
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                il[g] = mfma_4x4x1(wih[g][2 * q + 1], lo.z, il[g]);
-                hl[g] = mfma_4x4x1(whh[g][2 * q + 1], lo.w, hl[g]);
-                iu[g] = mfma_4x4x1(wih[g][17 + 2 * q], up.z, iu[g]);
-                hu[g] = mfma_4x4x1(whh[g][17 + 2 * q], up.w, hu[g]);
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const float wlc = c == 0 ? wl[g].x : (c == 1 ? wl[g].y : (c == 2 ? wl[g].z : wl[g].w));
+                    const float wuc = c == 0 ? wu[g].x : (c == 1 ? wu[g].y : (c == 2 ? wu[g].z : wu[g].w));
+                    il[g] = mfma_4x4x1(wlc, xa_lo[c], il[g]);
+                    hl[g] = mfma_4x4x1(whh[g][4 * q + c], xh_lo[c], hl[g]);
+                    iu[g] = mfma_4x4x1(wuc, xa_up[c], iu[g]);
+                    hu[g] = mfma_4x4x1(whh[g][16 + 4 * q + c], xh_up[c], hu[g]);
+                }
             }
         }
         wave_lds_sync();                                  // every lane holds what it needs of the old a / h rows

@@ -531,10 +531,12 @@ __device__ __forceinline__ void gru_mfma4_batch(const TanhEntry *tanh_tab, GruMf
     }
 }
 
-// 4 offspring per 256-thread workgroup (one copy of the tanh table), ONE wave per SIMD: the lane's 192 gate weights, the 12
-// accumulators of the interleaved chains and the operands of the k-pairs in flight want the whole register file.
+// 4 offspring per 256-thread workgroup (one copy of the tanh table), two waves per SIMD: W_hh (96 values per lane) in registers,
+// W_ih in the wave's LDS block (13.5 KB; two workgroups = 8 waves fill 158 of the CU's 160 KB).  With all 192 gate weights in
+// registers the kernel needed 360 of them, i.e. one wave per SIMD, and a lone wave ran the step's ~550 non-MFMA instructions
+// with every stall exposed: 4.01 ms against this form's -- see DESIGN.md section 4.
 template <typename EnvT, bool FIXED_LENGTH>
-__global__ __launch_bounds__(256, 1) void k_rollout_gru_mfma4(const float *__restrict__ theta, const float *__restrict__ init,
+__global__ __launch_bounds__(256, 2) void k_rollout_gru_mfma4(const float *__restrict__ theta, const float *__restrict__ init,
                                                               int init_per_offspring, int n_rows, int E, int P, int max_step,
                                                               uint32_t obs_mask, double *__restrict__ ep_return,
                                                               int32_t *__restrict__ ep_steps)

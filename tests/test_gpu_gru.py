@@ -137,7 +137,7 @@ def test_lander_gru_rollout_on_the_matrix_cores_bit_exact():
     es.close()
 
 
-@pytest.mark.parametrize("knobs", [{"SES_TUNING": "gru_ep_parallel_max=0"},
+@pytest.mark.parametrize("knobs", [{"SES_TUNING": "gru_ep_parallel_max=0,gru_mfma4_min_e=0"},
                                    {"SES_TUNING": "gru_ep_parallel_max=0,gru_mfma_min_e=1"},
                                    {"SES_TUNING": "gru_ep_parallel_max=0,gru_mfma4_min_e=1"},
                                    {"SES_TUNING": "gru_ep_parallel_max=1000000"},
@@ -189,6 +189,7 @@ def test_gru_lockstep_episode_batches(E):
     theta = (rng.randn(n, 6562) * 0.4).astype(np.float32)
     init = rng.uniform(-0.05, 0.05, (n, E, 4)).astype(np.float32)
     es = HipES("CartPole-v1", 4, 2, True, True, pomdp=True, max_step=150, eval_ep_num=E)
+    es.set_tuning("gru_mfma4_min_e", 0)                           # (7 and 8 episodes take the 4x4x1 MFMA step by default since round 6)
     o_fit, _, o_steps = co.rollout_cartpole(theta, init, E, 150, gru=True, obs_mask=0b1010)
     for mode in (0, 1):
         fit, _, ep_steps = es.rollout(dev(theta), dev(init), mode=mode, want_episodes=True)

@@ -19,6 +19,9 @@ python tools/collect_sq.py $TAG rollout k_rollout_cartpole_mlp gpurun_out/sq_mlp
 python tools/collect_sq.py $TAG gru_lockstep k_rollout_gru_lockstep gpurun_out/sq_gru/sq_1 gpurun_out/sq_gru/sq_2
 python tools/collect_sq.py $TAG c3_lander LanderLs gpurun_out/sqc3_1 gpurun_out/sqc3_2
 python tools/collect_sq.py $TAG gru_mfma k_rollout_gru_mfma gpurun_out/mf_1 gpurun_out/mf_2
+# round 6: the same counters for the 4x4x1 MFMA kernel (eval_ep_num 8)
+bash tools/prof_mfma.sh --eval-ep-num 8 > gpurun_out/sq_mfma4.txt 2>&1
+python tools/collect_sq.py $TAG gru_mfma4 k_rollout_gru_mfma4 gpurun_out/mf_1 gpurun_out/mf_2
 python tools/collect_sq.py $TAG box2d_mlp k_rollout_box2d_mlp gpurun_out/sqb2_1 gpurun_out/sqb2_2
 cp profiles/${TAG}_pmc_env_step.json profiles/${TAG}_sq_*.json $OUT/
 cp gpurun_out/kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
@@ -34,6 +37,7 @@ tools/envstep_ab 24 15 20 200 > $OUT/${TAG}_envstep_ab_final_box.txt 2>&1; head 
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 python bench.py --gru --no-extras --no-cpu-baseline > $OUT/${TAG}_bench_gru.json 2>> $OUT/bench.err
 python bench.py --gru --eval-ep-num 16 --no-extras --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_gru16.json 2>> $OUT/bench.err
+python bench.py --gru --eval-ep-num 8 --no-extras --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_gru8.json 2>> $OUT/bench.err
 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_flags.json 2>> $OUT/bench.err
 for cfg in cartpole_openai.yaml cartpole.yaml cartpole_pomdp_gru.yaml simplespread.yaml lunarlander_openai.yaml; do
   python tools/time_loop.py $cfg 2>&1 | tail -1
