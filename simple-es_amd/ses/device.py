@@ -55,6 +55,14 @@ def exclusive_stream(device=None):
     return torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", device))
 
 
+def destroy_stream(stream):
+    """Give back a stream of exclusive_stream() (ses_stream_destroy) once every handle built on it is closed.  A rig that
+    ends with such streams alive is fine by itself, but under rocprofv3 the HIP runtime's exit-time teardown of live
+    CU-masked streams runs after the profiler has finalised and the process ends in SIGSEGV (profiles/README.md, round 6)."""
+    stream.synchronize()
+    check(_lib.load().ses_stream_destroy(ctypes.c_void_p(stream.cuda_stream)), "ses_stream_destroy")
+
+
 class HipES:
     """One handle = one (env, network shape, device, stream).  Mirrors the constructor arguments of
     the reference's builder.build_env / build_network (builder.py:10-24)."""

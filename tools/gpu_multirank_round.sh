@@ -18,7 +18,7 @@ echo "float all-gather of the partials:" | tee -a gpurun_out/r06_time_tail_shard
 SES_TUNING=openai_granule_exchange=0 SES_TAIL_SHAPES=4x4096,4x8192 timeout -k 10 300 python tools/time_tail.py 2>&1 | grep "^{" | tee -a gpurun_out/r06_time_tail_sharded.txt
 for mode in 1 0; do
   rm -rf gpurun_out/prof_tail
-  (cd /tmp && export TMPDIR=/tmp && SES_TUNING=openai_granule_exchange=$mode SES_TAIL_SHAPES=8x4096,8x8192 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_tail -- python3 $R/tools/time_tail.py > $R/gpurun_out/prof_tail_$mode.txt 2>&1)
+  (cd /tmp && export TMPDIR=/tmp && SES_TUNING=openai_granule_exchange=$mode SES_TAIL_SHAPES=8x4096,8x8192 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_tail -- python3 $R/tools/time_tail.py > $R/gpurun_out/prof_tail_$mode.txt 2>&1; echo "rocprofv3 exit code $?")
   echo "== openai_granule_exchange=$mode"
   python tools/tail_by_kernel.py $(find gpurun_out/prof_tail -name "*kernel_trace.csv" | head -1)
 done > gpurun_out/r06_tail_by_kernel.txt 2>&1
