@@ -48,6 +48,23 @@ def test_single_rank_rccl_communicator_roundtrip():
     es.close()
 
 
+def test_exclusive_streams_come_and_go():
+    """ses_stream_create_exclusive / ses_stream_destroy: a handle works on such a stream, and a rig can give the stream back
+    (streams left alive end a rocprofv3 run in SIGSEGV at process exit: NOTES.md, round 6)."""
+    from ses import HipES, destroy_stream, exclusive_stream
+    for _ in range(3):
+        s = exclusive_stream()
+        es = HipES("CartPole-v1", 4, 2, True, False, max_step=20, eval_ep_num=2, stream=s)
+        with torch.cuda.stream(s):
+            theta = torch.zeros(64, es.P, device="cuda")
+            init = torch.full((es.E, es.init_dim), 0.01, device="cuda")
+            fit = es.rollout(theta, init)
+        s.synchronize()
+        assert fit.shape == (64,) and float(fit.min()) >= 1.0 and float(fit.max()) <= 20.0
+        es.close()
+        destroy_stream(s)
+
+
 def test_raw_abi_comm_error_paths():
     from ses import _lib
     lib = _lib.load()
